@@ -1,0 +1,137 @@
+/*
+ * include/mkt.h -- C ABI of libmkt_hip.so, the MI355X (gfx950) implementation of Microcket's
+ * sam2pairs hot path.  Plain C: opaque handle, POD structs, caller-visible pointers and sizes,
+ * int return codes, no exceptions, no torch types.
+ *
+ * What it replaces (paths relative to the reference tree):
+ *   src/sam2pairs/sam2pairs.cpp:23-228  main(): argv, batch loop, stdout/.sam writes, .log
+ *   src/sam2pairs/pairutil.h:136-177    load_batch(): per-line filter + QNAME run-length grouping
+ *   src/sam2pairs/pairutil.h:63-126     cigar2segment()
+ *   src/sam2pairs/pairutil.h:180-208    check_integrity_{1,2}_seg()
+ *   src/sam2pairs/flash2pairs.h:17-155  flash2pairs()
+ *   src/sam2pairs/unc2pairs.h:16-358    unc2pairs()
+ * The reference has no library boundary of its own: its plugin surface is the process contract
+ * of bin/sam2pairs (argv / stdin / stdout / <prefix>.<mode>.sam / <prefix>.<mode>2pairs.log,
+ * microcket:479,483,501,505).  The drop-in for THAT surface is the `sam2pairs` executable built
+ * from microcket_amd/csrc/sam2pairs_main.cpp, which is a thin host loop over this ABI.
+ * INTEGRATION.md shows both bindings.
+ *
+ * Threading: one context per GPU and per input stream; a context is not thread-safe.
+ * Every entry point fails with MKT_E_NO_DEVICE when no HIP device is usable: there is no CPU path.
+ */
+#ifndef MKT_H
+#define MKT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKT_ABI_VERSION 1
+
+enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
+
+enum {
+    MKT_OK = 0,
+    MKT_E_ARG = -1,          /* bad argument */
+    MKT_E_NO_DEVICE = -2,    /* no usable HIP device / kernel image not loadable */
+    MKT_E_HIP = -3,          /* a HIP call failed (mkt_last_error has the text) */
+    MKT_E_NOMEM = -4,
+    MKT_E_CAPACITY = -5,     /* a QNAME group does not fit the block buffer */
+    MKT_E_KERNEL = -6,       /* the kernel reported an internal error bit */
+    MKT_E_STATE = -7         /* call order violated (e.g. submit after finish) */
+};
+
+/* tile geometry selection (tests force the small-tile build to exercise every slow path) */
+enum { MKT_TILES_AUTO = 0, MKT_TILES_FAST = 1, MKT_TILES_SMALL = 2 };
+
+typedef struct mkt_params {
+    int32_t mode;              /* MKT_MODE_*                                   argv[2] */
+    float min_mapped_ratio;    /* float32, as (float)atof(argv[5])             sam2pairs.cpp:41 */
+    int32_t min_mapq;          /* atoi(argv[6]); compared unsigned             sam2pairs.cpp:44, pairutil.h:157 */
+    int32_t write_sam;         /* 0: argv[7] starts with N/n/0                 sam2pairs.cpp:47 */
+    int32_t ref_threads;       /* argv[4] (>= 2): only the logged selfCircle depends on it (quirk Q2) */
+    int32_t device;            /* HIP device ordinal */
+    uint64_t block_bytes;      /* bytes of SAM text per kernel pass, 0 = default (256 MiB); < 1 GiB */
+    int32_t tiles;             /* MKT_TILES_* */
+    int32_t reserved;
+} mkt_params;
+
+/* The 8 counters of <prefix>.<mode>2pairs.log in file order (sam2pairs.cpp:211-218), plus totals. */
+typedef struct mkt_stats {
+    uint32_t lowMap, manyHits, unpaired, selfCircle, trans, cis10K, cis1K, cis0;
+    uint32_t selfCircle_all;   /* every self-circle, before the thread-0 mask of quirk Q2 */
+    uint32_t reserved;
+    uint64_t groups;           /* K: surviving QNAME groups, including the last one (never classified, quirk Q1) */
+    uint64_t pairs;            /* .pairs lines */
+    uint64_t pair_bytes, sam_bytes;
+    uint64_t lines_in, bytes_in, blocks;
+} mkt_stats;
+
+typedef struct mkt_out {
+    const char* pairs; size_t pairs_len;   /* ready .pairs bytes (stdout of bin/sam2pairs) */
+    const char* sam;   size_t sam_len;     /* ready <prefix>.<mode>.sam bytes */
+} mkt_out;
+
+/* HIP-event timing of the kernels launched by a context (for bench.py's roofline object) */
+typedef struct mkt_timing {
+    double tile_kernel_ms;     /* sum over launches of the fused tile kernel */
+    uint64_t tile_launches;
+    uint64_t tile_bytes;       /* SAM bytes those launches consumed */
+    double other_ms;           /* memset + finish kernels */
+} mkt_timing;
+
+typedef struct mkt_ctx mkt_ctx;
+
+int mkt_abi_version(void);
+const char* mkt_strerror(int code);
+const char* mkt_last_error(const mkt_ctx* ctx);     /* ctx may be NULL: last create error */
+int mkt_device_count(void);
+
+int mkt_create(const mkt_params* p, mkt_ctx** out);
+void mkt_destroy(mkt_ctx* ctx);
+
+/* ---- streaming path: host bytes in, host bytes out (what the sam2pairs executable uses) -------
+ * mkt_submit takes the next bytes of the SAM stream in any chunking; `last` != 0 ends the input.
+ * Complete QNAME groups are processed on the GPU as soon as a block fills; mkt_drain hands back
+ * the output bytes that are final (everything except the newest group, see quirk Q1).  The
+ * pointers stay valid until the next call on the context. */
+int mkt_submit(mkt_ctx* ctx, const char* bytes, size_t n, int last);
+int mkt_drain(mkt_ctx* ctx, mkt_out* out);
+
+/* ---- resident path: text already in HBM (bench.py, multi-GPU shards) --------------------------
+ * The block must start on a QNAME-group boundary, end on a line end, be < 1 GiB and 16-byte
+ * aligned; d_text must stay valid until mkt_sync.  Output bytes stay on the device (fetch them
+ * with mkt_fetch_last_block) and results accumulate in the context exactly as for mkt_submit.
+ * The call is asynchronous on the context's stream. */
+int mkt_submit_device(mkt_ctx* ctx, const void* d_text, size_t n);
+int mkt_sync(mkt_ctx* ctx);
+int mkt_fetch_last_block(mkt_ctx* ctx, char* pairs, size_t pairs_cap, size_t* pairs_len,
+                         char* sam, size_t sam_cap, size_t* sam_len);
+
+/* ---- end of input ------------------------------------------------------------------------------
+ * drop_last != 0: this context saw the end of the whole input, so its last surviving group is
+ * dropped (quirk Q1).  For a sharded run only the shard holding the input's end passes 1.
+ * group_offset / total_groups place the shard's groups in the whole input for quirk Q2
+ * (single context: pass 0, 0 and the library uses its own count). */
+int mkt_finish(mkt_ctx* ctx, int drop_last, uint64_t group_offset, uint64_t total_groups, mkt_stats* st);
+/* formats the 8-line log exactly as sam2pairs.cpp:211-218; returns bytes written */
+int mkt_format_log(const mkt_stats* st, char* out, size_t cap);
+
+int mkt_get_timing(const mkt_ctx* ctx, mkt_timing* t);
+int mkt_reset_timing(mkt_ctx* ctx);
+
+/* ---- synthetic inputs (stand-in for util/simulation + BWA) ------------------------
+ * Generates groups [first_group, first_group + n_groups) of the seeded data set straight into
+ * device memory owned by the context; *d_text stays valid until the next mkt_synth_device call or
+ * mkt_destroy.  profile: 0 unc, 1 flash, 2 stress; genome: 0 hg38, 1 mm10. */
+int mkt_synth_device(mkt_ctx* ctx, uint64_t seed, int profile, int genome, int read_len, int lanes,
+                     uint64_t first_group, uint64_t n_groups, int tail_group,
+                     const void** d_text, size_t* n_bytes);
+int mkt_copy_to_host(mkt_ctx* ctx, const void* d_src, void* dst, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MKT_H */

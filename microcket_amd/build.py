@@ -1,0 +1,90 @@
+"""Build every native artefact of the package in-tree (no JIT caches, nothing in site-packages).
+
+    python -m microcket_amd.build            # library + executable
+    python -m microcket_amd.build --all      # + oracle, reference build, test tools
+
+libmkt_hip.so   hipcc --offload-arch=gfx950, hand-written HIP kernels + the C ABI (include/mkt.h)
+bin/sam2pairs   the drop-in executable (same argv as the reference's bin/sam2pairs)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmkt_hip.so")
+EXE = os.path.join(HERE, "bin", "sam2pairs")
+ARCH = "gfx950"
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd, **kw)
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU build of this package)")
+
+
+def build_lib(force=False):
+    srcs = [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_capi.cpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("mkt_core.h", "mkt_tile.h", "mkt_host.h", "mkt_launch.h", "mkt_synth.h")]
+    deps.append(os.path.join(ROOT, "include", "mkt.h"))
+    if force or _newer(LIB, deps):
+        _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function",
+              "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", LIB])
+    return LIB
+
+
+def build_exe(force=False):
+    src = os.path.join(CSRC, "sam2pairs_main.cpp")
+    if force or _newer(EXE, [src, LIB, os.path.join(ROOT, "include", "mkt.h")]):
+        os.makedirs(os.path.dirname(EXE), exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", EXE, "-L" + HERE, "-lmkt_hip",
+              "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    return EXE
+
+
+def build_oracle():
+    """Test infrastructure: CPU restatement (+ the reference itself when /root/reference is present)."""
+    _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def build_test_tools():
+    out = os.path.join(ROOT, "tests", "host", "_build")
+    os.makedirs(out, exist_ok=True)
+    emul = os.path.join(out, "libmkt_emul.so")
+    src = os.path.join(ROOT, "tests", "host", "tile_emul.cpp")
+    hdrs = [os.path.join(CSRC, f) for f in ("mkt_core.h", "mkt_tile.h", "mkt_host.h")]
+    if _newer(emul, [src] + hdrs):
+        _run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fPIC", "-shared", "-o", emul, src])
+    tout = os.path.join(ROOT, "tools", "_build")
+    os.makedirs(tout, exist_ok=True)
+    synth = os.path.join(tout, "synth_sam")
+    ssrc = os.path.join(ROOT, "tools", "synth_sam.cpp")
+    if _newer(synth, [ssrc, os.path.join(CSRC, "mkt_synth.h")]):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", synth, ssrc])
+
+
+def build_all(force=False, extras=True):
+    build_lib(force)
+    build_exe(force)
+    if extras:
+        build_oracle()
+        build_test_tools()
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, extras="--all" in sys.argv or True)

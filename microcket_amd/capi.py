@@ -1,0 +1,206 @@
+"""ctypes binding of include/mkt.h (libmkt_hip.so).  Plumbing only: no record is ever touched here."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+MODE_FLASH, MODE_UNC = 0, 1
+TILES_AUTO, TILES_FAST, TILES_SMALL = 0, 1, 2
+EXPORTS = [
+    "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
+    "mkt_submit", "mkt_drain", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
+    "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
+]
+
+
+class MktError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("min_mapped_ratio", C.c_float), ("min_mapq", C.c_int32), ("write_sam", C.c_int32),
+                ("ref_threads", C.c_int32), ("device", C.c_int32), ("block_bytes", C.c_uint64), ("tiles", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0",
+                                           "selfCircle_all", "reserved")] + \
+               [(k, C.c_uint64) for k in ("groups", "pairs", "pair_bytes", "sam_bytes", "lines_in", "bytes_in", "blocks")]
+
+    def counters(self):
+        return {k: getattr(self, k) for k in ("lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0")}
+
+
+class Out(C.Structure):
+    _fields_ = [("pairs", C.c_void_p), ("pairs_len", C.c_size_t), ("sam", C.c_void_p), ("sam_len", C.c_size_t)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("tile_kernel_ms", C.c_double), ("tile_launches", C.c_uint64), ("tile_bytes", C.c_uint64), ("other_ms", C.c_double)]
+
+
+def lib_path():
+    return os.path.join(HERE, "libmkt_hip.so")
+
+
+def exe_path():
+    return os.path.join(HERE, "bin", "sam2pairs")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libmkt_hip.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise MktError(f"{path} is missing: run `python -m microcket_amd.build` (hipcc, gfx950). No CPU path exists.")
+    L = C.CDLL(path)
+    L.mkt_strerror.restype = C.c_char_p
+    L.mkt_last_error.restype = C.c_char_p
+    L.mkt_last_error.argtypes = [C.c_void_p]
+    L.mkt_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+    L.mkt_destroy.argtypes = [C.c_void_p]
+    L.mkt_destroy.restype = None
+    L.mkt_submit.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]
+    L.mkt_drain.argtypes = [C.c_void_p, C.POINTER(Out)]
+    L.mkt_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mkt_sync.argtypes = [C.c_void_p]
+    L.mkt_fetch_last_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mkt_finish.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(Stats)]
+    L.mkt_format_log.argtypes = [C.POINTER(Stats), C.c_char_p, C.c_size_t]
+    L.mkt_get_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.mkt_reset_timing.argtypes = [C.c_void_p]
+    L.mkt_synth_device.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.mkt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(load_library().mkt_device_count())
+
+
+class Context:
+    """One GPU context = one input stream (mirrors one bin/sam2pairs process of the reference)."""
+
+    def __init__(self, mode, ratio=0.5, min_mapq=10, write_sam=True, ref_threads=4, device=0, block_bytes=0, tiles=TILES_AUTO):
+        self.L = load_library()
+        if isinstance(mode, str):
+            mode = {"flash": MODE_FLASH, "unc": MODE_UNC}[mode]
+        self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 0)
+        self.h = C.c_void_p()
+        rc = self.L.mkt_create(C.byref(self.params), C.byref(self.h))
+        if rc != 0:
+            raise MktError(f"mkt_create: {self.L.mkt_strerror(rc).decode()}: {self.L.mkt_last_error(None).decode()}")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MktError(f"{what}: {self.L.mkt_strerror(rc).decode()}: {self.L.mkt_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.L.mkt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- streaming path
+    def submit(self, data: bytes, last=False):
+        self._chk(self.L.mkt_submit(self.h, data, len(data), 1 if last else 0), "mkt_submit")
+
+    def drain(self):
+        o = Out()
+        self._chk(self.L.mkt_drain(self.h, C.byref(o)), "mkt_drain")
+        pairs = C.string_at(o.pairs, o.pairs_len) if o.pairs_len else b""
+        sam = C.string_at(o.sam, o.sam_len) if o.sam_len else b""
+        return pairs, sam
+
+    def finish(self, drop_last=True, group_offset=0, total_groups=0):
+        st = Stats()
+        self._chk(self.L.mkt_finish(self.h, 1 if drop_last else 0, group_offset, total_groups, C.byref(st)), "mkt_finish")
+        return st
+
+    def format_log(self, st):
+        buf = C.create_string_buffer(512)
+        self.L.mkt_format_log(C.byref(st), buf, 512)
+        return buf.value
+
+    def run_bytes(self, text: bytes, chunk=0):
+        """Whole input -> (pairs, sam, stats, log)."""
+        pairs, sam = [], []
+        if chunk <= 0:
+            chunk = max(len(text), 1)
+        pos = 0
+        while True:
+            part = text[pos:pos + chunk]
+            pos += len(part)
+            last = pos >= len(text)
+            self.submit(part, last)
+            a, b = self.drain()
+            pairs.append(a)
+            sam.append(b)
+            if last:
+                break
+        st = self.finish(True)
+        a, b = self.drain()
+        pairs.append(a)
+        sam.append(b)
+        return b"".join(pairs), b"".join(sam), st, self.format_log(st)
+
+    # ---- resident path
+    def synth_device(self, seed, profile, n_groups, first_group=0, genome=0, read_len=150, lanes=1, tail_group=False):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._chk(self.L.mkt_synth_device(self.h, seed, profile, genome, read_len, lanes, first_group, n_groups, 1 if tail_group else 0,
+                                          C.byref(p), C.byref(n)), "mkt_synth_device")
+        return p.value, n.value
+
+    def submit_device(self, d_ptr, n):
+        self._chk(self.L.mkt_submit_device(self.h, C.c_void_p(d_ptr), n), "mkt_submit_device")
+
+    def sync(self):
+        self._chk(self.L.mkt_sync(self.h), "mkt_sync")
+
+    def fetch_last_block(self):
+        np_, ns_ = C.c_size_t(), C.c_size_t()
+        self._chk(self.L.mkt_fetch_last_block(self.h, None, 0, C.byref(np_), None, 0, C.byref(ns_)), "mkt_fetch_last_block")
+        pb = C.create_string_buffer(max(np_.value, 1))
+        sb = C.create_string_buffer(max(ns_.value, 1))
+        self._chk(self.L.mkt_fetch_last_block(self.h, pb, np_.value, C.byref(np_), sb, ns_.value, C.byref(ns_)), "mkt_fetch_last_block")
+        return pb.raw[:np_.value], sb.raw[:ns_.value]
+
+    def copy_to_host(self, d_ptr, n):
+        buf = C.create_string_buffer(max(n, 1))
+        self._chk(self.L.mkt_copy_to_host(self.h, C.c_void_p(d_ptr), buf, n), "mkt_copy_to_host")
+        return buf.raw[:n]
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.L.mkt_get_timing(self.h, C.byref(t)), "mkt_get_timing")
+        return t
+
+    def reset_timing(self):
+        self._chk(self.L.mkt_reset_timing(self.h), "mkt_reset_timing")
+
+
+def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes", env=None, exe=None):
+    """Runs the drop-in executable with the reference's argv (microcket:479,483,501,505).  Returns (rc, stdout, stderr)."""
+    exe = exe or exe_path()
+    if not os.path.exists(exe):
+        raise MktError(f"{exe} is missing: run `python -m microcket_amd.build`")
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    p = subprocess.run([exe, in_sam, mode, prefix, str(threads), str(ratio), str(mapq), sam], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr

@@ -1,0 +1,453 @@
+// mkt_capi.cpp -- the C ABI of include/mkt.h: contexts, block scheduling, host bookkeeping.
+// Compiled with hipcc into libmkt_hip.so together with mkt_kernels.hip.  There is no CPU path:
+// every entry point needs a HIP device and fails loudly without one.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mkt.h"
+#include "mkt_launch.h"
+
+using namespace mkt;
+
+static thread_local std::string g_create_error;
+
+struct mkt_ctx {
+    mkt_params p;
+    Params P;
+    int cfg = CFG_FAST;
+    hipStream_t stream = nullptr;
+    size_t block_cap = 0;
+    // device
+    uint8_t* d_in = nullptr;
+    uint8_t* d_pairs = nullptr; size_t pairs_cap = 0;
+    uint8_t* d_sam = nullptr; size_t sam_cap = 0;
+    uint64_t* d_sc = nullptr; size_t sc_cap = 0;
+    uint8_t* d_ws = nullptr; size_t ws_cap = 0;
+    DevRun* d_run = nullptr;
+    // host (pinned)
+    uint8_t* h_in = nullptr; size_t h_len = 0;
+    BlockResult* h_res = nullptr; size_t res_slots = 0, res_used = 0, res_folded = 0;
+    std::vector<uint8_t> h_stage;       // D2H landing for block outputs
+    // streaming outputs
+    std::vector<char> out_pairs, out_sam, tail_pairs, tail_sam, drained_pairs, drained_sam;
+    RunAccum acc;
+    std::vector<uint64_t> sc_host;
+    bool input_done = false, finished = false;
+    uint64_t bytes_in = 0, blocks = 0;
+    size_t last_n = 0;                   // bytes of the last resident block
+    // timing
+    std::vector<hipEvent_t> ev;          // start/stop pairs of the tile kernel
+    std::vector<uint64_t> ev_bytes;
+    double folded_ms = 0; uint64_t folded_launches = 0, folded_bytes = 0;
+    // synth
+    char* d_syn = nullptr; size_t syn_cap = 0;
+    uint64_t* d_syn_sizes = nullptr; size_t syn_sizes_cap = 0;
+    std::string err;
+};
+
+static int fail(mkt_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                                                            \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail((c), MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+int mkt_abi_version(void) { return MKT_ABI_VERSION; }
+
+const char* mkt_strerror(int code) {
+    switch (code) {
+    case MKT_OK: return "ok";
+    case MKT_E_ARG: return "bad argument";
+    case MKT_E_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case MKT_E_HIP: return "HIP runtime error";
+    case MKT_E_NOMEM: return "out of memory";
+    case MKT_E_CAPACITY: return "a QNAME group does not fit the block buffer";
+    case MKT_E_KERNEL: return "kernel reported an internal error";
+    case MKT_E_STATE: return "call order violated";
+    default: return "unknown error";
+    }
+}
+const char* mkt_last_error(const mkt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mkt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static size_t ws_bytes_for(uint32_t ntiles) {
+    return (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast)) + 256 + sizeof(BlockResult);
+}
+static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
+    size_t need = ws_bytes_for(ntiles);
+    if (need <= c->ws_cap) return MKT_OK;
+    if (c->d_ws) HIPCHK(c, hipFree(c->d_ws));
+    c->d_ws = nullptr; c->ws_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_ws, need));
+    c->ws_cap = need;
+    return MKT_OK;
+}
+static int ensure_dev(mkt_ctx* c, uint8_t** p, size_t* cap, size_t need) {
+    if (need <= *cap) return MKT_OK;
+    if (*p) HIPCHK(c, hipFree(*p));
+    *p = nullptr; *cap = 0;
+    need += need / 8 + 4096;
+    HIPCHK(c, hipMalloc((void**)p, need));
+    *cap = need;
+    return MKT_OK;
+}
+
+int mkt_create(const mkt_params* p, mkt_ctx** out) {
+    if (!p || !out) return fail(nullptr, MKT_E_ARG, "null argument");
+    *out = nullptr;
+    if (p->mode != MKT_MODE_FLASH && p->mode != MKT_MODE_UNC) return fail(nullptr, MKT_E_ARG, "mode must be MKT_MODE_FLASH or MKT_MODE_UNC");
+    if (p->ref_threads < 2) return fail(nullptr, MKT_E_ARG, "ref_threads must be >= 2 (sam2pairs.cpp:36)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, MKT_E_NO_DEVICE, "no HIP device: libmkt_hip has no CPU path");
+    if (p->device < 0 || p->device >= ndev) return fail(nullptr, MKT_E_ARG, "device %d out of range (have %d)", p->device, ndev);
+    mkt_ctx* c = new mkt_ctx();
+    c->p = *p;
+    c->P.mode = p->mode; c->P.ratio = p->min_mapped_ratio; c->P.min_mapq = (uint32_t)p->min_mapq; c->P.write_sam = p->write_sam ? 1 : 0;
+    c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;
+    size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)256 << 20);
+    if (bc < 4096) bc = 4096;
+    if (bc >= ((size_t)1 << 30)) bc = ((size_t)1 << 30) - 4096;
+    bc = (bc + 15) & ~(size_t)15;
+    c->block_cap = bc;
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); mkt_destroy(c); return e_ == hipErrorOutOfMemory ? MKT_E_NOMEM : MKT_E_HIP; } } while (0)
+    CK(hipSetDevice(p->device));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CK(hipMalloc((void**)&c->d_run, sizeof(DevRun)));
+    CK(hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
+    c->res_slots = 1024;
+    CK(hipHostMalloc((void**)&c->h_res, c->res_slots * sizeof(BlockResult), hipHostMallocDefault));
+    CK(hipStreamSynchronize(c->stream));
+#undef CK
+    *out = c;
+    return MKT_OK;
+}
+
+void mkt_destroy(mkt_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->p.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    if (c->d_in) hipFree(c->d_in);
+    if (c->d_pairs) hipFree(c->d_pairs);
+    if (c->d_sam) hipFree(c->d_sam);
+    if (c->d_sc) hipFree(c->d_sc);
+    if (c->d_ws) hipFree(c->d_ws);
+    if (c->d_run) hipFree(c->d_run);
+    if (c->d_syn) hipFree(c->d_syn);
+    if (c->d_syn_sizes) hipFree(c->d_syn_sizes);
+    if (c->h_in) hipHostFree(c->h_in);
+    if (c->h_res) hipHostFree(c->h_res);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// enqueue one block: memset workspace, tile kernel (timed), finish kernel, result D2H into slot
+static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, size_t slot) {
+    if (((uintptr_t)d_text & 15u) != 0) return fail(c, MKT_E_ARG, "block text must be 16-byte aligned");
+    if (n >= ((size_t)1 << 30)) return fail(c, MKT_E_ARG, "block of %zu bytes: must be < 1 GiB", n);
+    const uint32_t ntiles = num_tiles((uint32_t)n, tile_bytes(cfg));
+    int rc = ensure_ws(c, ntiles);
+    if (rc) return rc;
+    // output capacities: .sam is at most the block (+1 for a missing final newline); .pairs is
+    // checked in-kernel and grown on demand (the result carries the exact size)
+    if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, n / 3 + 65536))) return rc;
+    if (c->P.write_sam && (rc = ensure_dev(c, &c->d_sam, &c->sam_cap, n + 64))) return rc;
+    if (!c->d_sc) {
+        size_t need = (size_t)1 << 22;          // 4 Mi self-circle indices; grown at sync if exceeded
+        HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
+        c->sc_cap = need;
+    }
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    uint8_t* w = c->d_ws;
+    a.text = d_text; a.n = (uint32_t)n; a.ntiles = ntiles; a.P = c->P;
+    a.descA = (uint64_t*)w; w += (size_t)ntiles * 8;
+    a.descB = (uint64_t*)w; w += (size_t)ntiles * 8;
+    a.descC = (uint64_t*)w; w += (size_t)ntiles * 8;
+    a.tile_last = (TileLast*)w; w += (size_t)ntiles * sizeof(TileLast);
+    a.ticket = (uint32_t*)w; w += 256;
+    a.res = (BlockResult*)w;
+    a.run = c->d_run;
+    a.out.pairs = c->d_pairs; a.out.pairs_cap = c->pairs_cap;
+    a.out.sam = c->d_sam; a.out.sam_cap = c->P.write_sam ? c->sam_cap : 0;
+    a.out.sc = c->d_sc; a.out.sc_cap = c->sc_cap;
+    HIPCHK(c, hipMemsetAsync(c->d_ws, 0, ws_bytes_for(ntiles), c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
+    int grid = (int)(ntiles < 1024u ? ntiles : 1024u);
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    HIPCHK(c, launch_tiles(a, cfg, grid, c->stream));
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, launch_finish(a, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&c->h_res[slot], a.res, sizeof(BlockResult), hipMemcpyDeviceToHost, c->stream));
+    return MKT_OK;
+}
+
+static void fold_timing(mkt_ctx* c) {       // stream must be idle
+    for (size_t k = 0; k + 1 < c->ev.size(); k += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]) == hipSuccess) { c->folded_ms += ms; ++c->folded_launches; c->folded_bytes += c->ev_bytes[k / 2]; }
+        hipEventDestroy(c->ev[k]); hipEventDestroy(c->ev[k + 1]);
+    }
+    c->ev.clear(); c->ev_bytes.clear();
+}
+
+static int check_result(mkt_ctx* c, const BlockResult& r) {
+    if (r.err == 0) return MKT_OK;
+    return fail(c, MKT_E_KERNEL, "kernel error bits 0x%x%s%s%s%s%s%s", r.err,
+                (r.err & E_LINE_TABLE) ? " [line table overflow: use MKT_TILES_SMALL]" : "",
+                (r.err & E_LOOKBACK) ? " [look-back timeout]" : "",
+                (r.err & E_PAIRS_CAP) ? " [.pairs buffer]" : "", (r.err & E_SAM_CAP) ? " [.sam buffer]" : "",
+                (r.err & E_SC_CAP) ? " [self-circle buffer]" : "", (r.err & E_FIELD_RANGE) ? " [field > 65535 bytes]" : "");
+}
+
+// run one host block synchronously, with the automatic retries (small tiles / bigger buffers)
+static int run_host_block(mkt_ctx* c, size_t n) {
+    int rc;
+    if (!c->d_in) { HIPCHK(c, hipMalloc((void**)&c->d_in, c->block_cap + 64)); }
+    HIPCHK(c, hipMemcpyAsync(c->d_in, c->h_in, n, hipMemcpyHostToDevice, c->stream));
+    int cfg = c->cfg;
+    BlockResult r;
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = enqueue_block(c, c->d_in, n, cfg, 0))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fold_timing(c);
+        r = c->h_res[0];
+        if (r.err == 0) break;
+        if (attempt >= 3) return check_result(c, r);
+        if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg == CFG_FAST && c->p.tiles == MKT_TILES_AUTO) { cfg = CFG_SMALL; continue; }
+        bool grew = false;
+        if (r.err & E_PAIRS_CAP) { if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, r.pair_bytes + 4096))) return rc; grew = true; }
+        if (r.err & E_SAM_CAP) { if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, r.sam_bytes + 4096))) return rc; grew = true; }
+        if (r.err & E_SC_CAP) {
+            size_t need = (size_t)(c->acc.sc + r.sc) * 2 + 4096;
+            uint64_t* nd = nullptr;
+            HIPCHK(c, hipMalloc((void**)&nd, need * sizeof(uint64_t)));
+            HIPCHK(c, hipMemcpy(nd, c->d_sc, (size_t)c->acc.sc * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+            HIPCHK(c, hipFree(c->d_sc));
+            c->d_sc = nd; c->sc_cap = need; grew = true;
+        }
+        if (!grew) return check_result(c, r);
+    }
+    // fetch outputs
+    c->acc.add_block(r);
+    ++c->blocks;
+    size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
+    if (c->h_stage.size() < pb + sb) c->h_stage.resize(pb + sb);
+    if (pb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data(), c->d_pairs, pb, hipMemcpyDeviceToHost, c->stream));
+    if (sb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + pb, c->d_sam, sb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (r.last.valid) {
+        // the previous newest group is now final: release its bytes, hold back the new newest group's
+        c->out_pairs.insert(c->out_pairs.end(), c->tail_pairs.begin(), c->tail_pairs.end());
+        c->out_sam.insert(c->out_sam.end(), c->tail_sam.begin(), c->tail_sam.end());
+        size_t tp = r.last.pair_bytes, ts = c->P.write_sam ? r.last.sam_bytes : 0;
+        const char* hp = (const char*)c->h_stage.data();
+        c->out_pairs.insert(c->out_pairs.end(), hp, hp + (pb - tp));
+        c->tail_pairs.assign(hp + (pb - tp), hp + pb);
+        c->out_sam.insert(c->out_sam.end(), hp + pb, hp + pb + (sb - ts));
+        c->tail_sam.assign(hp + pb + (sb - ts), hp + pb + sb);
+    }
+    return MKT_OK;
+}
+
+int mkt_submit(mkt_ctx* c, const char* bytes, size_t n, int last) {
+    if (!c) return MKT_E_ARG;
+    if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "submit after the end of input");
+    if (n && !bytes) return fail(c, MKT_E_ARG, "null bytes");
+    HIPCHK(c, hipSetDevice(c->p.device));
+    if (!c->h_in) HIPCHK(c, hipHostMalloc((void**)&c->h_in, c->block_cap + 64, hipHostMallocDefault));
+    size_t pos = 0;
+    c->bytes_in += n;
+    for (;;) {
+        size_t space = c->block_cap - c->h_len;
+        size_t take = n - pos < space ? n - pos : space;
+        if (take) { memcpy(c->h_in + c->h_len, bytes + pos, take); c->h_len += take; pos += take; }
+        const bool all_in = pos == n;
+        if (c->h_len == c->block_cap && !(all_in && last)) {
+            size_t cut = group_aligned_prefix((const char*)c->h_in, c->h_len);
+            if (cut == 0) return fail(c, MKT_E_CAPACITY, "no QNAME-group boundary inside a %zu-byte block: raise block_bytes", c->block_cap);
+            int rc = run_host_block(c, cut);
+            if (rc) return rc;
+            memmove(c->h_in, c->h_in + cut, c->h_len - cut);
+            c->h_len -= cut;
+            continue;
+        }
+        if (all_in) break;
+    }
+    if (last) {
+        if (c->h_len) { int rc = run_host_block(c, c->h_len); if (rc) return rc; c->h_len = 0; }
+        c->input_done = true;
+    }
+    return MKT_OK;
+}
+
+int mkt_drain(mkt_ctx* c, mkt_out* out) {
+    if (!c || !out) return MKT_E_ARG;
+    c->drained_pairs.swap(c->out_pairs); c->out_pairs.clear();
+    c->drained_sam.swap(c->out_sam); c->out_sam.clear();
+    out->pairs = c->drained_pairs.data(); out->pairs_len = c->drained_pairs.size();
+    out->sam = c->drained_sam.data(); out->sam_len = c->drained_sam.size();
+    return MKT_OK;
+}
+
+int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
+    if (!c) return MKT_E_ARG;
+    if (c->finished) return fail(c, MKT_E_STATE, "submit after finish");
+    if (!d_text && n) return fail(c, MKT_E_ARG, "null device pointer");
+    HIPCHK(c, hipSetDevice(c->p.device));
+    if (c->res_used == c->res_slots) { int rc = mkt_sync(c); if (rc) return rc; }
+    int rc = enqueue_block(c, (const uint8_t*)d_text, n, c->cfg, c->res_used);
+    if (rc) return rc;
+    ++c->res_used;
+    c->last_n = n;
+    c->bytes_in += n;
+    return MKT_OK;
+}
+
+int mkt_sync(mkt_ctx* c) {
+    if (!c) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fold_timing(c);
+    int rc = MKT_OK;
+    for (size_t k = c->res_folded; k < c->res_used; ++k) {
+        const BlockResult& r = c->h_res[k];
+        if (r.err) { rc = check_result(c, r); break; }      // resident blocks are not retried: fail loudly
+        c->acc.add_block(r);
+        ++c->blocks;
+    }
+    c->res_used = 0; c->res_folded = 0;
+    return rc;
+}
+
+int mkt_fetch_last_block(mkt_ctx* c, char* pairs, size_t pairs_cap, size_t* pairs_len, char* sam, size_t sam_cap, size_t* sam_len) {
+    if (!c) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the last folded result is not kept per block; re-read it from the device workspace
+    BlockResult r;
+    const uint32_t ntiles = num_tiles((uint32_t)c->last_n, tile_bytes(c->cfg));
+    const uint8_t* w = c->d_ws + (size_t)ntiles * (3 * 8 + sizeof(TileLast)) + 256;
+    HIPCHK(c, hipMemcpy(&r, w, sizeof r, hipMemcpyDeviceToHost));
+    if (pairs_len) *pairs_len = (size_t)r.pair_bytes;
+    if (sam_len) *sam_len = c->P.write_sam ? (size_t)r.sam_bytes : 0;
+    if (pairs && r.pair_bytes) {
+        if (pairs_cap < r.pair_bytes) return fail(c, MKT_E_ARG, "pairs buffer too small (%llu needed)", (unsigned long long)r.pair_bytes);
+        HIPCHK(c, hipMemcpy(pairs, c->d_pairs, (size_t)r.pair_bytes, hipMemcpyDeviceToHost));
+    }
+    if (sam && c->P.write_sam && r.sam_bytes) {
+        if (sam_cap < r.sam_bytes) return fail(c, MKT_E_ARG, "sam buffer too small (%llu needed)", (unsigned long long)r.sam_bytes);
+        HIPCHK(c, hipMemcpy(sam, c->d_sam, (size_t)r.sam_bytes, hipMemcpyDeviceToHost));
+    }
+    return MKT_OK;
+}
+
+int mkt_finish(mkt_ctx* c, int drop_last, uint64_t group_offset, uint64_t total_groups, mkt_stats* st) {
+    if (!c || !st) return MKT_E_ARG;
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    c->sc_host.resize((size_t)c->acc.sc);
+    if (c->acc.sc) HIPCHK(c, hipMemcpy(c->sc_host.data(), c->d_sc, (size_t)c->acc.sc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    const uint64_t K = total_groups ? total_groups : c->acc.groups;
+    RunStats s = c->acc.finish(drop_last != 0, (uint32_t)c->p.ref_threads, group_offset, K, c->sc_host.data());
+    memset(st, 0, sizeof *st);
+    st->lowMap = s.counters[C_LOWMAP]; st->manyHits = s.counters[C_MANYHITS]; st->unpaired = s.counters[C_UNPAIRED];
+    st->selfCircle = s.counters[C_SELFCIRCLE]; st->trans = s.counters[C_TRANS];
+    st->cis10K = s.counters[C_CIS10K]; st->cis1K = s.counters[C_CIS1K]; st->cis0 = s.counters[C_CIS0];
+    st->selfCircle_all = s.selfcircle_all;
+    st->groups = s.groups; st->pairs = s.pairs; st->pair_bytes = s.pair_bytes; st->sam_bytes = s.sam_bytes;
+    st->bytes_in = c->bytes_in; st->blocks = c->blocks;
+    if (!c->finished) {
+        if (!drop_last) {           // the newest group is final after all: release it
+            c->out_pairs.insert(c->out_pairs.end(), c->tail_pairs.begin(), c->tail_pairs.end());
+            c->out_sam.insert(c->out_sam.end(), c->tail_sam.begin(), c->tail_sam.end());
+        }
+        c->tail_pairs.clear(); c->tail_sam.clear();
+        c->finished = true;
+    }
+    return MKT_OK;
+}
+
+int mkt_format_log(const mkt_stats* st, char* out, size_t cap) {
+    if (!st || !out) return MKT_E_ARG;
+    return snprintf(out, cap, "lowMap\t%u\nmanyHits\t%u\nunpaired\t%u\nselfCircle\t%u\ntrans\t%u\ncis10K\t%u\ncis1K\t%u\ncis0\t%u\n",
+                    st->lowMap, st->manyHits, st->unpaired, st->selfCircle, st->trans, st->cis10K, st->cis1K, st->cis0);
+}
+
+int mkt_get_timing(const mkt_ctx* c, mkt_timing* t) {
+    if (!c || !t) return MKT_E_ARG;
+    t->tile_kernel_ms = c->folded_ms; t->tile_launches = c->folded_launches; t->tile_bytes = c->folded_bytes; t->other_ms = 0;
+    return MKT_OK;
+}
+int mkt_reset_timing(mkt_ctx* c) {
+    if (!c) return MKT_E_ARG;
+    c->folded_ms = 0; c->folded_launches = 0; c->folded_bytes = 0;
+    return MKT_OK;
+}
+
+int mkt_synth_device(mkt_ctx* c, uint64_t seed, int profile, int genome, int read_len, int lanes, uint64_t first_group,
+                     uint64_t n_groups, int tail_group, const void** d_text, size_t* n_bytes) {
+    if (!c || !d_text || !n_bytes) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    SynParams sp;
+    sp.seed = seed; sp.profile = profile; sp.genome = genome; sp.read_len = read_len; sp.lanes = lanes;
+    if (c->syn_sizes_cap < n_groups + 2) {
+        if (c->d_syn_sizes) HIPCHK(c, hipFree(c->d_syn_sizes));
+        c->d_syn_sizes = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_syn_sizes, (n_groups + 2) * sizeof(uint64_t)));
+        c->syn_sizes_cap = n_groups + 2;
+    }
+    uint64_t* d_total = c->d_syn_sizes + n_groups;
+    HIPCHK(c, launch_synth_sizes(sp, first_group, n_groups, c->d_syn_sizes, c->stream));
+    HIPCHK(c, launch_exscan(c->d_syn_sizes, n_groups, d_total, c->stream));
+    uint64_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t tail = tail_group ? synth_tail_bytes(sp) : 0;
+    size_t need = (size_t)total + tail + 64;
+    if (c->syn_cap < need) {
+        if (c->d_syn) HIPCHK(c, hipFree(c->d_syn));
+        c->d_syn = nullptr; c->syn_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_syn, need));
+        c->syn_cap = need;
+    }
+    HIPCHK(c, launch_synth_write(sp, first_group, n_groups, c->d_syn_sizes, c->d_syn, c->stream));
+    if (tail) HIPCHK(c, launch_synth_tail(sp, c->d_syn + total, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *d_text = c->d_syn;
+    *n_bytes = (size_t)total + tail;
+    return MKT_OK;
+}
+
+int mkt_copy_to_host(mkt_ctx* c, const void* d_src, void* dst, size_t n) {
+    if (!c || !d_src || !dst) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    HIPCHK(c, hipMemcpy(dst, d_src, n, hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+}  // extern "C"

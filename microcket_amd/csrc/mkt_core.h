@@ -1,0 +1,368 @@
+// mkt_core.h -- per-line and per-group logic of the sam2pairs hot path, written once for the
+// gfx950 kernels (mkt_kernels.hip) and for the host-side tile emulation used by the CPU tests
+// (tests/host/tile_emul.cpp).  Nothing here is a product CPU path: the library only ever runs
+// this code inside HIP kernels.
+//
+// Reference behaviour restated (paths relative to /root/reference/src/sam2pairs/):
+//   record tokenising + per-line filter   pairutil.h:152-161, sam2pairs.cpp:116-126
+//   CIGAR walk                            pairutil.h:63-126
+//   integrity tests (float32, quirk Q3)   pairutil.h:180-208
+//   stitched classifier                   flash2pairs.h:17-155
+//   unstitched classifier                 unc2pairs.h:16-358
+//   ordering / self-circle / bins         flash2pairs.h:105-144, unc2pairs.h:310-348
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MKT_HD __host__ __device__ inline
+#else
+#define MKT_HD inline
+#endif
+
+namespace mkt {
+
+constexpr int kMinClip = 20;          // pairutil.h:54
+constexpr int kMaxSelfCircle = 10;    // pairutil.h:57
+constexpr int kMaxPairDist = 1000;    // pairutil.h:58
+constexpr uint32_t kRefBatch = 1u << 18;   // pairutil.h:48 (only quirk Q2 depends on it)
+constexpr uint32_t kUnknown = 0xFFFFFFFFu;
+
+enum Counter : uint32_t { C_NONE = 0, C_LOWMAP, C_MANYHITS, C_UNPAIRED, C_SELFCIRCLE, C_TRANS, C_CIS10K, C_CIS1K, C_CIS0, C_COUNT };
+enum Mode : int { MODE_FLASH = 0, MODE_UNC = 1 };
+
+struct Params {
+    int mode;
+    float ratio;          // min_mapped_ratio as float32 (sam2pairs.cpp:41)
+    uint32_t min_mapq;    // compared unsigned (pairutil.h:157)
+    int write_sam;
+};
+
+// Block text in global memory plus the on-chip window [w0, w0 + wlen) of it.
+struct TextView {
+    const uint8_t* g;     // block base
+    uint32_t n;           // block bytes
+    const uint8_t* win;   // window copy (LDS on the GPU)
+    uint32_t w0, wlen;
+    MKT_HD uint8_t at(uint32_t off) const {
+        uint32_t r = off - w0;
+        return r < wlen ? win[r] : g[off];
+    }
+};
+
+MKT_HD bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }   // classic-locale isspace
+
+// One alignment record: the six leading SAM fields, CIGAR already folded into segments.
+struct Rec {
+    uint32_t off;              // line start, block relative
+    uint32_t qn_off, qn_len;   // QNAME, relative to line start
+    uint32_t rn_off, rn_len;   // RNAME, relative to line start
+    uint32_t flag, pos, mapq;
+    int32_t segCnt, lclip, rclip, mappable;   // pairutil.h:29-38
+    int32_t left0, left1, right0, right1;     // first two segments (more are never consumed)
+    int32_t rightLast;                        // right[segCnt-1] for segCnt <= 2, else unused
+    bool survive;              // six well-formed tokens and passes the FLAG/MAPQ filter
+};
+
+// Parses the record starting at `off`.  Stops after the sixth token; never reads at or past the
+// line's '\n'.  Token rules follow `ss >> a >> b ...` (whitespace-separated, leading blanks skipped).
+// A record with fewer than six tokens, a non-decimal FLAG/POS/MAPQ or a header line ('@') does
+// not survive (the reference's behaviour on such lines is undefined / input-order dependent).
+MKT_HD Rec parse_record(const TextView& tv, uint32_t off, const Params& P) {
+    Rec r;
+    r.off = off; r.qn_off = r.qn_len = r.rn_off = r.rn_len = 0;
+    r.flag = r.pos = r.mapq = 0;
+    r.segCnt = 0; r.lclip = r.rclip = r.mappable = 0;
+    r.left0 = r.left1 = r.right0 = r.right1 = r.rightLast = 0;
+    r.survive = false;
+    const uint32_t n = tv.n;
+    uint32_t p = off;
+    if (p >= n) return r;
+    bool header = tv.at(p) == '@';
+    bool ok = !header;
+    for (int k = 0; k < 6; ++k) {
+        uint8_t c = 0;
+        while (p < n) { c = tv.at(p); if (c == '\n' || !is_ws(c)) break; ++p; }
+        if (p >= n || c == '\n') return r;          // fewer than six tokens
+        const uint32_t ts = p;
+        if (k == 1 || k == 3 || k == 4) {           // FLAG, POS, MAPQ: unsigned decimal
+            uint64_t v = 0;
+            while (p < n) {
+                c = tv.at(p);
+                if (c == '\n' || is_ws(c)) break;
+                if (c < '0' || c > '9' || v > 0xFFFFFFFFull) ok = false;
+                v = v * 10 + (uint64_t)(c - '0');
+                ++p;
+            }
+            if (v > 0xFFFFFFFFull) ok = false;
+            if (k == 1) r.flag = (uint32_t)v; else if (k == 3) r.pos = (uint32_t)v; else r.mapq = (uint32_t)v;
+        } else if (k == 5) {                        // CIGAR -> segments, pairutil.h:63-126
+            int32_t index = 0, value = 0, cur = (int32_t)r.pos, lastRight = 0;
+            bool bad = false;
+            r.left0 = (int32_t)r.pos;
+            while (p < n) {
+                c = tv.at(p);
+                if (c == '\n' || is_ws(c)) break;
+                ++p;
+                if (bad) continue;
+                if (c >= '0' && c <= '9') { value = value * 10 + (int32_t)(c - '0'); continue; }
+                if (c == 'H' || c == 'S') {
+                    uint8_t nx = p < n ? tv.at(p) : (uint8_t)'\n';
+                    bool lastChar = (nx == '\n' || is_ws(nx));
+                    if (lastChar) r.rclip = value;
+                    else if (index == 0) r.lclip = value;
+                    else bad = true;
+                } else if (c == 'M' || c == 'D') {
+                    if (c == 'M') r.mappable += value;
+                    cur += value;
+                    lastRight = cur - 1;
+                    if (index == 0) r.right0 = lastRight; else if (index == 1) r.right1 = lastRight;
+                } else if (c == 'I') {
+                } else if (c == 'N') {
+                    cur += value;
+                    ++index;
+                    lastRight = 0;
+                    if (index == 1) { r.left1 = cur; r.right1 = 0; }
+                } else {
+                    bad = true;
+                }
+                value = 0;
+            }
+            if (!bad && lastRight != 0) {
+                r.segCnt = index + 1;
+                r.rightLast = lastRight;
+            }
+        } else {                                    // QNAME, RNAME
+            while (p < n) { c = tv.at(p); if (c == '\n' || is_ws(c)) break; ++p; }
+            if (k == 0) { r.qn_off = ts - off; r.qn_len = p - ts; } else { r.rn_off = ts - off; r.rn_len = p - ts; }
+        }
+    }
+    r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;
+    return r;
+}
+
+// bytewise std::string::compare of two byte ranges of the block
+MKT_HD int text_cmp(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
+    uint32_t m = alen < blen ? alen : blen;
+    for (uint32_t i = 0; i < m; ++i) {
+        int d = (int)tv.at(a + i) - (int)tv.at(b + i);
+        if (d) return d;
+    }
+    return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+MKT_HD bool text_eq(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
+    if (alen != blen) return false;
+    for (uint32_t i = 0; i < alen; ++i)
+        if (tv.at(a + i) != tv.at(b + i)) return false;
+    return true;
+}
+
+// The segment part of a record, as the classifiers consume it.
+struct Seg {
+    int32_t segCnt, lclip, rclip, mappable, left0, left1, right0, right1, rightLast;
+    uint32_t flag, pos;
+    uint32_t chr_off, chr_len;    // RNAME bytes, block relative
+};
+MKT_HD Seg seg_of(const Rec& r) {
+    Seg s;
+    s.segCnt = r.segCnt; s.lclip = r.lclip; s.rclip = r.rclip; s.mappable = r.mappable;
+    s.left0 = r.left0; s.left1 = r.left1; s.right0 = r.right0; s.right1 = r.right1; s.rightLast = r.rightLast;
+    s.flag = r.flag; s.pos = r.pos; s.chr_off = r.off + r.rn_off; s.chr_len = r.rn_len;
+    return s;
+}
+
+// float32 compare, one rounding for the product (cvtsi2ss / mulss / comiss in the reference)
+MKT_HD bool ratio_ok(int32_t mappable, int32_t total, float ratio) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float rhs = __fmul_rn((float)total, ratio);
+#else
+    volatile float rhs = (float)total * ratio;
+#endif
+    return (float)mappable >= rhs;
+}
+MKT_HD bool integrity_1(const Seg& s, float ratio) {            // pairutil.h:180-188
+    int32_t total = s.mappable;
+    if (s.lclip > kMinClip) total += s.lclip;
+    if (s.rclip > kMinClip) total += s.rclip;
+    return ratio_ok(s.mappable, total, ratio);
+}
+MKT_HD bool integrity_2(const Seg& a, const Seg& b, float ratio) {   // pairutil.h:190-208
+    int32_t t1 = a.mappable, t2 = b.mappable;
+    if (a.lclip > kMinClip) t1 += a.lclip;
+    if (a.rclip > kMinClip) t1 += a.rclip;
+    if (b.lclip > kMinClip) t2 += b.lclip;
+    if (a.rclip > kMinClip) t2 += b.rclip;                      // quirk Q3 (pairutil.h:200)
+    return ratio_ok(a.mappable + b.mappable, t1 > t2 ? t1 : t2, ratio);
+}
+
+struct Verdict {
+    uint32_t counter;          // Counter
+    bool emit;
+    uint32_t chrA_off, chrA_len, chrB_off, chrB_len;
+    uint32_t posA, posB;
+    uint8_t sA, sB;
+};
+MKT_HD Verdict verdict_none(uint32_t counter) {
+    Verdict v;
+    v.counter = counter; v.emit = false;
+    v.chrA_off = v.chrA_len = v.chrB_off = v.chrB_len = 0; v.posA = v.posB = 0; v.sA = v.sB = '+';
+    return v;
+}
+MKT_HD uint8_t strand_of(uint32_t flag) { return (flag & 16u) ? '-' : '+'; }
+
+// flash2pairs.h:110-144 / unc2pairs.h:315-348
+MKT_HD Verdict order_and_bin(const TextView& tv, uint32_t c1o, uint32_t c1l, uint32_t pos1, uint8_t s1,
+                             uint32_t c2o, uint32_t c2l, uint32_t pos2, uint8_t s2) {
+    Verdict v;
+    int chrcmp = text_cmp(tv, c1o, c1l, c2o, c2l);
+    if (chrcmp < 0 || (chrcmp == 0 && pos1 < pos2)) {
+        v.chrA_off = c1o; v.chrA_len = c1l; v.posA = pos1; v.sA = s1;
+        v.chrB_off = c2o; v.chrB_len = c2l; v.posB = pos2; v.sB = s2;
+    } else {
+        v.chrA_off = c2o; v.chrA_len = c2l; v.posA = pos2; v.sA = s2;
+        v.chrB_off = c1o; v.chrB_len = c1l; v.posB = pos1; v.sB = s1;
+    }
+    v.emit = true;
+    if (chrcmp == 0) {
+        uint32_t dist = v.posB - v.posA;
+        if (dist <= (uint32_t)kMaxSelfCircle) { v.counter = C_SELFCIRCLE; v.emit = false; }
+        else v.counter = dist >= 10000u ? C_CIS10K : (dist >= 1000u ? C_CIS1K : C_CIS0);
+    } else {
+        v.counter = C_TRANS;
+    }
+    return v;
+}
+
+// flash2pairs.h:17-155.  n = surviving records in the group, a/b = the first two.
+MKT_HD Verdict classify_flash(const TextView& tv, uint32_t n, const Seg& a, const Seg& b, float ratio) {
+    if (n == 1) {
+        if (a.segCnt > 2) return verdict_none(C_MANYHITS);
+        if (!integrity_1(a, ratio)) return verdict_none(C_LOWMAP);
+        uint32_t pos1 = a.pos;
+        uint32_t pos2 = a.segCnt >= 1 ? (uint32_t)a.rightLast : 0u;     // right[segCnt-1]; UB in the reference when segCnt == 0
+        uint32_t dist = pos2 - pos1;
+        Verdict v;
+        v.counter = dist >= 10000u ? C_CIS10K : (dist >= 1000u ? C_CIS1K : C_CIS0);
+        v.emit = true;
+        v.chrA_off = v.chrB_off = a.chr_off; v.chrA_len = v.chrB_len = a.chr_len;
+        v.posA = pos1; v.posB = pos2; v.sA = '+'; v.sB = '-';
+        return v;
+    }
+    if (n == 2) {
+        if (a.segCnt != 1 || b.segCnt != 1) return verdict_none(C_MANYHITS);
+        if (!integrity_2(a, b, ratio)) return verdict_none(C_LOWMAP);
+        uint32_t pos1 = a.pos, pos2 = b.pos;
+        if (a.lclip > a.rclip) pos1 = (uint32_t)a.right0;
+        if (b.lclip > b.rclip) pos2 = (uint32_t)b.right0;
+        return order_and_bin(tv, a.chr_off, a.chr_len, pos1, strand_of(a.flag), b.chr_off, b.chr_len, pos2, strand_of(b.flag));
+    }
+    return verdict_none(C_MANYHITS);
+}
+
+MKT_HD bool pairable(const TextView& tv, const Seg& x, const Seg& y, int32_t lo_left, int32_t hi_left, int32_t hi_right) {
+    return text_cmp(tv, x.chr_off, x.chr_len, y.chr_off, y.chr_len) == 0 && lo_left < hi_left && hi_right - lo_left <= kMaxPairDist;
+}
+MKT_HD uint32_t clip_side_pos(const Seg& s) { return (uint32_t)(s.lclip > s.rclip ? s.right0 : s.left0); }
+
+// unc2pairs.h:16-358.  n1/n2 = records with FLAG&64 / (else) FLAG&128; r1a,r1b / r2a,r2b = the first two of each.
+MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const Seg& r1a, const Seg& r1b,
+                            const Seg& r2a, const Seg& r2b, float ratio) {
+    if (n1 == 0 || n2 == 0) return verdict_none(C_NONE);        // :52-55
+    if (n1 + n2 > 3) return verdict_none(C_NONE);               // :56-59
+    uint32_t c1o, c1l, c2o, c2l, pos1 = 0, pos2 = 0;
+    uint8_t st1, st2;
+    if (n1 == 1 && n2 == 1) {                                   // category 0
+        const Seg& s1 = r1a; const Seg& s2 = r2a;
+        if (!integrity_1(s1, ratio)) return verdict_none(C_LOWMAP);
+        if (!integrity_1(s2, ratio)) return verdict_none(C_LOWMAP);
+        if (s1.segCnt + s2.segCnt > 3) return verdict_none(C_MANYHITS);
+        st1 = strand_of(s1.flag); st2 = strand_of(s2.flag);
+        c1o = s1.chr_off; c1l = s1.chr_len; c2o = s2.chr_off; c2l = s2.chr_len;
+        if (s1.segCnt == 1 && s2.segCnt == 1) {
+            pos1 = (uint32_t)(st1 == '+' ? s1.left0 : s1.right0);
+            pos2 = (uint32_t)(st2 == '+' ? s2.left0 : s2.right0);
+        } else if (s1.segCnt == 2) {
+            if (st1 == '+') {
+                if (st2 == '-' && pairable(tv, s1, s2, s1.left1, s2.left0, s2.right0)) { pos1 = (uint32_t)s1.left0; pos2 = (uint32_t)s2.right0; }
+                else return verdict_none(C_UNPAIRED);
+            } else {
+                if (st2 == '+' && pairable(tv, s1, s2, s2.left0, s1.left0, s1.right0)) { pos1 = (uint32_t)s1.right1; pos2 = (uint32_t)s2.left0; }
+                else return verdict_none(C_UNPAIRED);
+            }
+        } else {
+            if (st1 == '+') {
+                if (st2 == '-' && pairable(tv, s1, s2, s1.left0, s2.left0, s2.right0)) { pos1 = (uint32_t)s1.left0; pos2 = (uint32_t)s2.right1; }
+                else return verdict_none(C_UNPAIRED);
+            } else {
+                if (st2 == '+' && pairable(tv, s1, s2, s2.left1, s1.left0, s1.right0)) { pos1 = (uint32_t)s1.right0; pos2 = (uint32_t)s2.left0; }
+                else return verdict_none(C_UNPAIRED);
+            }
+        }
+    } else {
+        // categories 1 (1+2) and 2 (2+1): `u` is the read with one record, v0/v1 the split read
+        const bool cat1 = (n1 == 1);
+        const Seg& u = cat1 ? r1a : r2a;
+        const Seg& v0 = cat1 ? r2a : r1a;
+        const Seg& v1 = cat1 ? r2b : r1b;
+        if (cat1) {                                             // :62-98
+            if (!integrity_1(u, ratio)) return verdict_none(C_LOWMAP);
+            if (!integrity_2(v0, v1, ratio)) return verdict_none(C_LOWMAP);
+        } else {                                                // :100-121
+            if (!integrity_2(v0, v1, ratio)) return verdict_none(C_LOWMAP);
+            if (!integrity_1(u, ratio)) return verdict_none(C_LOWMAP);
+        }
+        if (u.segCnt != 1 || v0.segCnt != 1 || v1.segCnt != 1) return verdict_none(C_MANYHITS);
+        const uint8_t su = strand_of(u.flag);
+        uint32_t posu = 0;
+        int mate = -1;
+        for (int k = 0; k < 2 && mate < 0; ++k) {               // :196-227 / :255-285
+            const Seg& w = k == 0 ? v0 : v1;
+            if (su == '+') {
+                if (strand_of(w.flag) == '-' && pairable(tv, u, w, u.left0, w.left0, w.right0)) { posu = (uint32_t)u.left0; mate = k; }
+            } else {
+                if (strand_of(w.flag) == '+' && pairable(tv, u, w, w.left0, u.left0, u.right0)) { posu = (uint32_t)u.right0; mate = k; }
+            }
+        }
+        if (mate < 0) return verdict_none(C_UNPAIRED);          // :229-232 / :287-290
+        const Seg& o = mate == 0 ? v1 : v0;                     // the OTHER record of the split read
+        const uint32_t poso = clip_side_pos(o);
+        if (cat1) { c1o = u.chr_off; c1l = u.chr_len; pos1 = posu; st1 = su; c2o = o.chr_off; c2l = o.chr_len; pos2 = poso; st2 = strand_of(o.flag); }
+        else      { c2o = u.chr_off; c2l = u.chr_len; pos2 = posu; st2 = su; c1o = o.chr_off; c1l = o.chr_len; pos1 = poso; st1 = strand_of(o.flag); }
+    }
+    return order_and_bin(tv, c1o, c1l, pos1, st1, c2o, c2l, pos2, st2);
+}
+
+MKT_HD uint32_t dec_digits(uint32_t v) {
+    return v >= 1000000000u ? 10 : v >= 100000000u ? 9 : v >= 10000000u ? 8 : v >= 1000000u ? 7 : v >= 100000u ? 6
+         : v >= 10000u ? 5 : v >= 1000u ? 4 : v >= 100u ? 3 : v >= 10u ? 2 : 1;
+}
+// rid \t chrA \t posA \t chrB \t posB \t sA \t sB \n   (flash2pairs.h:123-127)
+MKT_HD uint32_t pair_line_len(uint32_t qn_len, const Verdict& v) {
+    return qn_len + v.chrA_len + v.chrB_len + dec_digits(v.posA) + dec_digits(v.posB) + 9u;   // 6 tabs, 2 strands, newline
+}
+template <class Sink> MKT_HD void put_dec(Sink& s, uint32_t v) {
+    uint32_t d = dec_digits(v);
+    uint32_t div = 1;
+    for (uint32_t i = 1; i < d; ++i) div *= 10u;
+    for (uint32_t i = 0; i < d; ++i) { s.put((uint8_t)('0' + (v / div) % 10u)); div /= 10u; }
+}
+template <class Sink> MKT_HD void put_text(Sink& s, const TextView& tv, uint32_t off, uint32_t len) {
+    for (uint32_t i = 0; i < len; ++i) s.put(tv.at(off + i));
+}
+template <class Sink> MKT_HD void format_pair(Sink& s, const TextView& tv, uint32_t qn_abs, uint32_t qn_len, const Verdict& v) {
+    put_text(s, tv, qn_abs, qn_len); s.put('\t');
+    put_text(s, tv, v.chrA_off, v.chrA_len); s.put('\t'); put_dec(s, v.posA); s.put('\t');
+    put_text(s, tv, v.chrB_off, v.chrB_len); s.put('\t'); put_dec(s, v.posB); s.put('\t');
+    s.put(v.sA); s.put('\t'); s.put(v.sB); s.put('\n');
+}
+
+// Quirk Q2: does surviving group g of K contribute to the LOGGED selfCircle?
+MKT_HD bool selfcircle_logged(uint64_t g, uint64_t K, uint32_t ref_threads) {
+    uint64_t j = g / kRefBatch, i = g % kRefBatch;
+    bool final = K <= (j + 1) * (uint64_t)kRefBatch;
+    uint64_t loaded = final ? (K - 1 - j * (uint64_t)kRefBatch) : (uint64_t)kRefBatch;
+    uint64_t W = final ? (uint64_t)ref_threads : (uint64_t)(ref_threads - 1);
+    return i < loaded / W;
+}
+
+}  // namespace mkt

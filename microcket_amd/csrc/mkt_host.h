@@ -1,0 +1,114 @@
+// mkt_host.h -- host-side bookkeeping around the per-block kernel results.
+//
+// The kernel classifies EVERY QNAME group of every block.  What the reference does across the
+// whole input lives here, on a few bytes per block:
+//   Q1  the input's last surviving group is never classified (pairutil.h:151-176 returns the last
+//       index, sam2pairs.cpp:150-151 uses it as a count) -> the newest group's counter, .pairs
+//       bytes and .sam bytes stay "pending" until a later group supersedes it, and are dropped at
+//       the end of the input;
+//   Q2  the logged selfCircle is reference-thread 0's share (sam2pairs.cpp:202-210 vs :214) ->
+//       evaluated from the global indices of the self-circle groups once K is known.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "mkt_tile.h"
+
+namespace mkt {
+
+struct BlockResult {            // written by the device (finish kernel), POD
+    uint64_t groups, emitted, sc, pair_bytes, sam_bytes;
+    uint32_t counters[C_COUNT];
+    uint32_t err;
+    TileLast last;              // last group of the block (valid = 0: the block holds no group)
+    uint32_t tiles, pad;
+};
+
+struct RunStats {               // what the .log needs, plus bookkeeping
+    uint32_t counters[C_COUNT]; // C_SELFCIRCLE holds the LOGGED value (Q2)
+    uint32_t selfcircle_all;
+    uint64_t groups;            // K: surviving groups seen, including the one Q1 drops
+    uint64_t pairs;             // emitted .pairs lines
+    uint64_t pair_bytes, sam_bytes;
+};
+
+struct RunAccum {
+    uint64_t groups = 0, emitted = 0, pair_bytes = 0, sam_bytes = 0;
+    uint64_t counters[C_COUNT] = {0};
+    uint64_t sc = 0;                   // self-circle groups so far (their indices live in the sc list)
+    TileLast pending = {0, 0, 0, 0};   // newest group (its bytes are the tail of the output so far)
+
+    void add_block(const BlockResult& r) {
+        sc += r.sc;
+        for (int c = 0; c < (int)C_COUNT; ++c) counters[c] += r.counters[c];
+        groups += r.groups; emitted += r.emitted; pair_bytes += r.pair_bytes; sam_bytes += r.sam_bytes;
+        if (r.last.valid) pending = r.last;
+    }
+    // drop_last: this shard holds the input's last group (Q1).  group_offset / K_total place the
+    // shard in the whole input (single process: 0 and `groups`).
+    // sc_idx: shard-local indices of the self-circle groups, in input order (`sc` entries).
+    RunStats finish(bool drop_last, uint32_t ref_threads, uint64_t group_offset, uint64_t K_total, const uint64_t* sc_idx) const {
+        RunStats s;
+        memset(&s, 0, sizeof s);
+        uint64_t c[C_COUNT];
+        for (int k = 0; k < (int)C_COUNT; ++k) c[k] = counters[k];
+        uint64_t n_sc = sc;
+        s.pairs = emitted; s.pair_bytes = pair_bytes; s.sam_bytes = sam_bytes;
+        if (drop_last && pending.valid) {
+            if (pending.counter) --c[pending.counter];
+            if (pending.counter == C_SELFCIRCLE && n_sc) --n_sc;      // it is the newest entry
+            if (pending.pair_bytes) { --s.pairs; s.pair_bytes -= pending.pair_bytes; s.sam_bytes -= pending.sam_bytes; }
+        }
+        uint64_t logged = 0;
+        for (uint64_t k = 0; k < n_sc; ++k)
+            if (selfcircle_logged(group_offset + sc_idx[k], K_total, ref_threads)) ++logged;
+        for (int k = 0; k < (int)C_COUNT; ++k) s.counters[k] = (uint32_t)c[k];     // u32 wrap as the reference's kstat
+        s.selfcircle_all = (uint32_t)c[C_SELFCIRCLE];
+        s.counters[C_SELFCIRCLE] = (uint32_t)logged;
+        s.groups = groups;
+        return s;
+    }
+};
+
+// the 8-line log of sam2pairs.cpp:211-218
+inline int format_log(const RunStats& s, char* out, size_t cap) {
+    return snprintf(out, cap, "lowMap\t%u\nmanyHits\t%u\nunpaired\t%u\nselfCircle\t%u\ntrans\t%u\ncis10K\t%u\ncis1K\t%u\ncis0\t%u\n",
+                    s.counters[C_LOWMAP], s.counters[C_MANYHITS], s.counters[C_UNPAIRED], s.counters[C_SELFCIRCLE],
+                    s.counters[C_TRANS], s.counters[C_CIS10K], s.counters[C_CIS1K], s.counters[C_CIS0]);
+}
+
+// Host cut: the largest prefix of buf[0, n) that ends on a line end AND on a QNAME change, so that
+// the next block starts a new group (lines of one read are contiguous in name-grouped SAM).
+// Returns 0 when no such boundary exists inside the buffer.
+inline size_t group_aligned_prefix(const char* buf, size_t n) {
+    auto is_ws_c = [](char c) { return c == ' ' || (c >= 9 && c <= 13); };
+    auto qname = [&](size_t ls, size_t le, size_t* a, size_t* b) {     // first token of [ls, le)
+        size_t p = ls;
+        while (p < le && is_ws_c(buf[p])) ++p;
+        *a = p;
+        while (p < le && !is_ws_c(buf[p])) ++p;
+        *b = p;
+    };
+    if (n == 0) return 0;
+    size_t end = n;                                   // exclusive end of complete lines
+    while (end > 0 && buf[end - 1] != '\n') --end;
+    if (end == 0) return 0;
+    // last complete line is [ls, end-1)
+    size_t le = end - 1, ls = le;
+    while (ls > 0 && buf[ls - 1] != '\n') --ls;
+    size_t ca, cb;
+    qname(ls, le, &ca, &cb);
+    while (ls > 0) {
+        size_t ple = ls - 1, pls = ple;
+        while (pls > 0 && buf[pls - 1] != '\n') --pls;
+        size_t pa, pb;
+        qname(pls, ple, &pa, &pb);
+        bool same = (pb - pa) == (cb - ca) && memcmp(buf + pa, buf + ca, cb - ca) == 0;
+        if (!same) return ls;                         // cut in front of the last run of equal names
+        ls = pls; ca = pa; cb = pb;
+    }
+    return 0;
+}
+
+}  // namespace mkt

@@ -1,0 +1,357 @@
+// mkt_kernels.hip -- gfx950 kernels of the sam2pairs hot path.
+//
+// k_tiles: ONE fused pass over a block of SAM text.  A workgroup draws tiles from an atomic
+// ticket, stages tile + halos in LDS with 16-byte loads, finds line starts with a SWAR newline
+// mask + workgroup scan, then runs the phases of mkt_tile.h one work item per lane (parse six
+// fields + CIGAR, group-start test, group walk + classification, in-tile exclusive sums), obtains
+// its output offsets from a decoupled look-back over per-tile descriptors (single 8-byte words
+// carrying their own flag, relaxed agent-scope atomics) and writes .pairs bytes (LDS-staged),
+// the pass-through .sam bytes, self-circle group indices and the 8 counters.
+// Text is read from HBM once (plus halos); outputs are written once; everything else is on chip.
+//
+// No MFMA: this is byte/integer work bounded by HBM bandwidth (DESIGN.md has the byte budget).
+#include <hip/hip_runtime.h>
+#include "mkt_launch.h"
+
+namespace mkt {
+
+constexpr int NT = 256;                      // 4 waves per workgroup
+constexpr uint64_t FLAG_AGG = 1ull << 62, FLAG_PREFIX = 2ull << 62, PAYLOAD = (1ull << 62) - 1;
+constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
+
+struct ScanScratch { uint64_t a[NT / 64], b[NT / 64]; };
+
+__device__ inline uint64_t shfl_up64(uint64_t v, int d) { return (uint64_t)__shfl_up((long long)v, d, 64); }
+__device__ inline uint64_t shfl_xor64(uint64_t v, int d) { return (uint64_t)__shfl_xor((long long)v, d, 64); }
+
+// exclusive scan of two u64 lanes-values over the workgroup; totals returned to every thread
+__device__ inline void block_exscan2(uint64_t& a, uint64_t& b, uint64_t& ta, uint64_t& tb, ScanScratch& sc) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t xa = shfl_up64(ia, d), xb = shfl_up64(ib, d);
+        if (lane >= d) { ia += xa; ib += xb; }
+    }
+    if (lane == 63) { sc.a[wv] = ia; sc.b[wv] = ib; }
+    __syncthreads();
+    uint64_t pa = 0, pb = 0;
+    ta = 0; tb = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wv) { pa += sc.a[w]; pb += sc.b[w]; }
+        ta += sc.a[w]; tb += sc.b[w];
+    }
+    a = pa + ia - a;
+    b = pb + ib - b;
+    __syncthreads();
+}
+
+// exact per-byte "== '\n'" mask of a dword, one bit per byte
+__device__ inline uint32_t nl_bits(uint32_t x) {
+    uint32_t y = x ^ 0x0A0A0A0Au;
+    uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);    // 0x80 where the byte is zero
+    return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+}
+
+// Decoupled look-back on one descriptor word per tile.  Executed by one full wave.
+__device__ inline uint64_t lookback(uint64_t* desc, uint32_t t, uint64_t agg, uint32_t* err_word) {
+    const int lane = threadIdx.x & 63;
+    if (t == 0) {
+        if (lane == 0) __hip_atomic_store(&desc[0], FLAG_PREFIX | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&desc[t], FLAG_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    int64_t j = (int64_t)t - 1;
+    uint32_t spins = 0;
+    for (;;) {
+        const int64_t idx = j - lane;
+        uint64_t w = FLAG_PREFIX;                           // tiles before the first have prefix 0
+        if (idx >= 0) w = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t flag = (uint32_t)(w >> 62);
+        const uint64_t m_prefix = __ballot(flag == 2);
+        const uint64_t m_invalid = __ballot(flag == 0);
+        const int first = m_prefix ? __builtin_ctzll(m_prefix) : 64;
+        const uint64_t needed = first >= 63 ? ~0ull : ((1ull << (first + 1)) - 1);
+        if (m_invalid & needed) {
+            if (++spins > LOOKBACK_SPIN_LIMIT) { if (lane == 0) atomicOr(err_word, (uint32_t)E_LOOKBACK); break; }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        uint64_t c = lane <= first ? (w & PAYLOAD) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) c += shfl_xor64(c, d);
+        excl += c;
+        if (first < 64) break;
+        j -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&desc[t], FLAG_PREFIX | ((excl + agg) & PAYLOAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
+template <class Cfg>
+__global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
+    __shared__ TileState<Cfg> st;
+    __shared__ uint16_t nlmask[Cfg::W / 16];
+    __shared__ ScanScratch scan;
+    __shared__ uint32_t s_tile;
+    constexpr int NVEC = Cfg::W / 16;
+    constexpr int VPT = (NVEC + NT - 1) / NT;          // newline-mask words per thread
+    constexpr int IPT = (Cfg::LCAP + NT - 1) / NT;     // line-table items per thread in the sums
+    const int tid = threadIdx.x;
+    const Params P = a.P;
+    const uint32_t n = a.n;
+    OutPtrs out = a.out;
+    out.group_base = a.run->groups;       // written by the previous block's k_finish (stream order)
+    out.sc_base = a.run->sc;
+
+    for (;;) {
+        if (tid == 0) { s_tile = atomicAdd(a.ticket, 1u); tile_reset(st); }
+        __syncthreads();
+        const uint32_t t = s_tile;
+        if (t >= a.ntiles) break;
+        const TileGeom G = tile_geom<Cfg>(t, n);
+        const uint32_t wlen = G.w1 - G.w0;
+        const uint32_t nvec = (wlen + 15u) >> 4;
+        TextView tv;
+        tv.g = a.text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = wlen;
+
+        // ---- stage window in LDS, build the newline mask -------------------------------------
+        for (uint32_t v = tid; v < nvec; v += NT) {
+            const uint32_t go = G.w0 + (v << 4);
+            uint4 x;
+            if (go + 16u <= n) {
+                x = *reinterpret_cast<const uint4*>(a.text + go);
+            } else {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint32_t b = 0; go + b < n; ++b) w[b >> 2] |= (uint32_t)a.text[go + b] << ((b & 3u) * 8u);
+                x = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            *reinterpret_cast<uint4*>(&st.win[v << 4]) = x;
+            uint32_t m = nl_bits(x.x) | (nl_bits(x.y) << 4) | (nl_bits(x.z) << 8) | (nl_bits(x.w) << 12);
+            // a '\n' at window position r opens a line at r+1: keep r <= wlen-2 only
+            const uint32_t r0 = v << 4;
+            if (r0 + 16u > wlen - 1u) {
+                const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u;     // valid bit count
+                m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u);
+            }
+            nlmask[v] = (uint16_t)m;
+        }
+        __syncthreads();
+
+        // ---- line table: exclusive scan of newline counts ------------------------------------
+        {
+            uint64_t cnt = 0, dummy = 0, total, td;
+            const uint32_t v0 = tid * VPT;
+            for (uint32_t k = 0; k < (uint32_t)VPT; ++k) if (v0 + k < nvec) cnt += __popc((uint32_t)nlmask[v0 + k]);
+            uint64_t ex = cnt;
+            block_exscan2(ex, dummy, total, td, scan);
+            const uint32_t lead = G.w0 == 0 ? 1u : 0u;
+            const uint32_t NL = (uint32_t)total + lead;
+            if (NL > (uint32_t)Cfg::LCAP) {
+                if (tid == 0) { st.err |= E_LINE_TABLE; st.NL = 0; st.first_idx = 0; st.end_idx = 0; }
+            } else {
+                uint32_t idx = (uint32_t)ex + lead;
+                for (uint32_t k = 0; k < (uint32_t)VPT; ++k) {
+                    if (v0 + k >= nvec) break;
+                    uint32_t m = nlmask[v0 + k];
+                    while (m) {
+                        const uint32_t b = __builtin_ctz(m);
+                        st.off[idx++] = G.w0 + ((v0 + k) << 4) + b + 1u;
+                        m &= m - 1u;
+                    }
+                }
+                if (tid == 0) { if (lead) st.off[0] = 0; st.NL = NL; st.first_idx = NL; st.end_idx = NL; }
+            }
+        }
+        __syncthreads();
+        const uint32_t NL = st.NL;
+
+        for (uint32_t i = tid; i < NL; i += NT) ph_parse(st, tv, P, G, i);
+        __syncthreads();
+        const uint32_t first_idx = st.first_idx, end_idx = st.end_idx;
+        for (uint32_t i = first_idx + tid; i < NL; i += NT) ph_start(st, tv, P, i);
+        __syncthreads();
+        for (uint32_t i = first_idx + tid; i < end_idx; i += NT) ph_group(st, tv, P, G, i);
+        __syncthreads();
+
+        // ---- exclusive sums over the tile's groups ---------------------------------------------
+        {
+            uint64_t ca = 0, cb = 0;                       // ca: groups | emitted<<16 | sc<<32 ; cb: pair | sam<<32
+            const uint32_t i0 = first_idx + tid * IPT;
+            for (uint32_t k = 0; k < (uint32_t)IPT; ++k) {
+                const uint32_t i = i0 + k;
+                if (i >= end_idx) break;
+                const uint32_t info = st.g_info[i];
+                if (info & GI_START) ca += 1ull;
+                if (info & GI_EMIT) ca += 1ull << 16;
+                if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ca += 1ull << 32;
+                cb += (uint64_t)st.g_plen[i] | ((uint64_t)st.g_slen[i] << 32);
+            }
+            uint64_t ea = ca, eb = cb, ta, tb;
+            block_exscan2(ea, eb, ta, tb, scan);
+            for (uint32_t k = 0; k < (uint32_t)IPT; ++k) {
+                const uint32_t i = i0 + k;
+                if (i >= end_idx) break;
+                st.x_grp[i] = (uint16_t)(ea & 0xFFFFu); st.x_emit[i] = (uint16_t)((ea >> 16) & 0xFFFFu); st.x_sc[i] = (uint16_t)((ea >> 32) & 0xFFFFu);
+                st.x_pair[i] = (uint32_t)eb; st.x_sam[i] = (uint32_t)(eb >> 32);
+                const uint32_t info = st.g_info[i];
+                if (info & GI_START) ea += 1ull;
+                if (info & GI_EMIT) ea += 1ull << 16;
+                if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ea += 1ull << 32;
+                eb += (uint64_t)st.g_plen[i] | ((uint64_t)st.g_slen[i] << 32);
+            }
+            if (tid == 0) {
+                st.sums.groups = (uint32_t)(ta & 0xFFFFu); st.sums.emitted = (uint32_t)((ta >> 16) & 0xFFFFu); st.sums.sc = (uint32_t)((ta >> 32) & 0xFFFFu);
+                st.sums.pair_bytes = (uint32_t)tb; st.sums.sam_bytes = tb >> 32;
+            }
+        }
+        __syncthreads();
+
+        // ---- block-wide exclusive prefix: three descriptor words, one wave each ----------------
+        {
+            const int wv = tid >> 6;
+            if (wv == 0) {
+                uint64_t ex = lookback(a.descA, t, ((uint64_t)st.sums.groups << 31) | st.sums.emitted, &a.res->err);
+                if ((tid & 63) == 0) { st.base.groups = (uint32_t)(ex >> 31); st.base.emitted = (uint32_t)(ex & 0x7FFFFFFFu); }
+            } else if (wv == 1) {
+                uint64_t ex = lookback(a.descB, t, ((uint64_t)st.sums.pair_bytes << 31) | st.sums.sc, &a.res->err);
+                if ((tid & 63) == 0) { st.base.pair_bytes = (uint32_t)(ex >> 31); st.base.sc = (uint32_t)(ex & 0x7FFFFFFFu); }
+            } else if (wv == 2) {
+                uint64_t ex = lookback(a.descC, t, st.sums.sam_bytes, &a.res->err);
+                if ((tid & 63) == 0) st.base.sam_bytes = ex;
+            }
+        }
+        __syncthreads();
+
+        // ---- emit ------------------------------------------------------------------------------
+        for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
+            ph_emit(st, tv, P, out, i);
+            ph_last(st, &a.tile_last[t], i);
+        }
+        __syncthreads();
+        {   // staged .pairs bytes -> global
+            const uint32_t used = st.stg_used;
+            const uint64_t go = st.base.pair_bytes;
+            if (go + used <= out.pairs_cap) { for (uint32_t k = tid; k < used; k += NT) out.pairs[go + k] = st.stg[k]; }
+            else if (tid == 0 && used) st.err |= E_PAIRS_CAP;
+        }
+        if (P.write_sam) {   // contiguous groups: straight byte-range copies
+            for (uint32_t i = first_idx; i < end_idx; ++i) {
+                const uint32_t info = st.g_info[i];
+                if ((info & (GI_EMIT | GI_CONTIG)) != (GI_EMIT | GI_CONTIG)) continue;
+                const uint32_t len = st.g_slen[i], src = st.off[i];
+                const uint64_t go = st.base.sam_bytes + st.x_sam[i];
+                if (go + len <= out.sam_cap) { for (uint32_t k = tid; k < len; k += NT) out.sam[go + k] = tv.at(src + k); }
+                else if (tid == 0) st.err |= E_SAM_CAP;
+            }
+        }
+        __syncthreads();
+        if (tid < (int)C_COUNT && st.cnt[tid]) atomicAdd(&a.res->counters[tid], st.cnt[tid]);
+        if (tid == 0 && st.err) atomicOr(&a.res->err, st.err);
+        __syncthreads();
+    }
+}
+
+// totals + the block's last group (quirk Q1 bookkeeping happens on the host)
+__global__ void k_finish(KArgs a) {
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_last = -1;
+    __syncthreads();
+    int best = -1;
+    for (uint32_t t = tid; t < a.ntiles; t += blockDim.x) if (a.tile_last[t].valid) best = (int)t;
+    if (best >= 0) atomicMax(&s_last, best);
+    __syncthreads();
+    if (tid == 0) {
+        BlockResult* r = a.res;
+        if (a.ntiles) {
+            const uint64_t A = a.descA[a.ntiles - 1] & PAYLOAD, B = a.descB[a.ntiles - 1] & PAYLOAD, C = a.descC[a.ntiles - 1] & PAYLOAD;
+            r->groups = A >> 31; r->emitted = A & 0x7FFFFFFFu;
+            r->pair_bytes = B >> 31; r->sc = B & 0x7FFFFFFFu;
+            r->sam_bytes = C;
+        }
+        if (s_last >= 0) r->last = a.tile_last[s_last];
+        r->tiles = a.ntiles;
+        if (r->err == 0) { a.run->groups += r->groups; a.run->sc += r->sc; }     // a failed block is re-run
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+typedef TileCfg<16384, 1024, 4096, 256, 4, 4096> CfgFast;
+typedef TileCfg<256, 64, 192, 512, 4, 512> CfgSmall;
+
+uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : CfgFast::TILE; }
+
+hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
+    if (a.ntiles == 0) return hipSuccess;
+    if (cfg == CFG_SMALL) hipLaunchKernelGGL(k_tiles<CfgSmall>, dim3(grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL(k_tiles<CfgFast>, dim3(grid), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_finish(const KArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic SAM: sizes, then bytes (offsets from an exclusive scan done between the two kernels)
+__global__ void k_synth_sizes(SynParams p, uint64_t first, uint64_t n, uint64_t* sizes) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SynCountSink c;
+    synth_group(c, p, first + i);
+    sizes[i] = c.n;
+}
+__global__ void k_synth_write(SynParams p, uint64_t first, uint64_t n, const uint64_t* offs, char* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    SynMemSink m{out + offs[i]};
+    synth_group(m, p, first + i);
+}
+// single-workgroup chained exclusive scan (generator only; not on the hot path)
+__global__ void k_exscan_u64(uint64_t* v, uint64_t n, uint64_t* total) {
+    __shared__ ScanScratch sc;
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += NT) {
+        uint64_t i = base + threadIdx.x;
+        uint64_t x = i < n ? v[i] : 0, d = 0, tx, td;
+        uint64_t e = x;
+        block_exscan2(e, d, tx, td, sc);
+        if (i < n) v[i] = carry + e;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tx;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+__global__ void k_synth_tail(SynParams p, char* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { SynMemSink m{out}; synth_tail_group(m, p); }
+}
+
+hipError_t launch_synth_sizes(const SynParams& p, uint64_t first, uint64_t n, uint64_t* sizes, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_synth_sizes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, first, n, sizes);
+    return hipGetLastError();
+}
+hipError_t launch_exscan(uint64_t* v, uint64_t n, uint64_t* total, hipStream_t s) {
+    hipLaunchKernelGGL(k_exscan_u64, dim3(1), dim3(NT), 0, s, v, n, total);
+    return hipGetLastError();
+}
+hipError_t launch_synth_write(const SynParams& p, uint64_t first, uint64_t n, const uint64_t* offs, char* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_synth_write, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, first, n, offs, out);
+    return hipGetLastError();
+}
+hipError_t launch_synth_tail(const SynParams& p, char* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_synth_tail, dim3(1), dim3(64), 0, s, p, out);
+    return hipGetLastError();
+}
+size_t synth_tail_bytes(const SynParams& p) {
+    SynCountSink c;
+    synth_tail_group(c, p);
+    return c.n;
+}
+
+}  // namespace mkt

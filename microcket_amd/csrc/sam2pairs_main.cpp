@@ -1,0 +1,108 @@
+// sam2pairs_main.cpp -- drop-in for the reference's bin/sam2pairs (src/sam2pairs/sam2pairs.cpp):
+// same positional arguments, same stderr messages, same exit codes, pairs on stdout,
+// <prefix>.<mode>.sam and <prefix>.<mode>2pairs.log side files.  All record processing happens
+// on the GPU behind the C ABI of include/mkt.h; this file only moves bytes.
+//
+//   sam2pairs <in.sam|/dev/stdin> <flash|unc> <out.prefix> [thread=4] [min_mapped_ratio=0.5] [min.mapQ=10] [sam=1|0]
+//
+// Environment (extensions, never needed by the microcket driver):
+//   MKT_DEVICE       HIP device ordinal (default 0)
+//   MKT_BLOCK_MB     SAM megabytes per GPU pass (default 256)
+//   MKT_TILES        auto | fast | small
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+#include "../../include/mkt.h"
+
+int main(int argc, char* argv[]) {
+    if (argc < 4) {     // sam2pairs.cpp:24-31
+        std::cerr << "\nUsage: " << argv[0] << " <in.sam> <mode=flash|unc> <out.prefix> [thread=4] [min_mapped_ratio=0.5] [min.mapQ=10] [sam=1|0]"
+                  << "\n\nTask: extract the pairs from the alignment result (MI355X build)."
+                  << "\n2 files will be written: out.mode2pairs.log and out.mode.sam."
+                  << "\nThe pairs (without header) will be output to stdout (to pipe with sort utility)."
+                  << "\n\nThis program is part of Microcket, and is NOT supposed to be called manually by the user.\n\n";
+        return 2;
+    }
+    mkt_params p;
+    memset(&p, 0, sizeof p);
+    p.ref_threads = 4; p.min_mapped_ratio = 0.5f; p.min_mapq = 10; p.write_sam = 1;
+    if (argc > 4) {     // sam2pairs.cpp:33-54
+        p.ref_threads = atoi(argv[4]);
+        if (p.ref_threads < 2) { std::cerr << "Error: at least 2 threads are required.\n"; return 5; }
+        if (argc > 5) {
+            p.min_mapped_ratio = (float)atof(argv[5]);
+            std::cerr << "INFO: min_mapped_ratio is set to " << p.min_mapped_ratio << ".\n";
+            if (argc > 6) {
+                p.min_mapq = atoi(argv[6]);
+                std::cerr << "INFO: min_mapQ is set to " << p.min_mapq << ".\n";
+                if (argc > 7 && (argv[7][0] == 'N' || argv[7][0] == 'n' || argv[7][0] == '0')) {
+                    p.write_sam = 0;
+                    std::cerr << "WARN: sam output is skipped.\n";
+                }
+            }
+        }
+    }
+    std::string mode = argv[2];     // sam2pairs.cpp:59-67
+    if (mode == "flash") p.mode = MKT_MODE_FLASH;
+    else if (mode == "unc") p.mode = MKT_MODE_UNC;
+    else { std::cerr << "Error: Unknown mode, must be 'flash' or 'unc'.\n"; return 6; }
+
+    FILE* fin = fopen(argv[1], "rb");     // sam2pairs.cpp:70-75
+    if (!fin) { std::cerr << "Error: read input file failed!\n"; return 10; }
+
+    std::string base = std::string(argv[3]) + "." + argv[2];
+    FILE* fsam = nullptr;
+    if (p.write_sam) {     // sam2pairs.cpp:82-91
+        fsam = fopen((base + ".sam").c_str(), "wb");
+        if (!fsam) { std::cerr << "Error: write sam file failed!\n"; fclose(fin); return 11; }
+    }
+
+    const char* e;
+    p.device = (e = getenv("MKT_DEVICE")) ? atoi(e) : 0;
+    p.block_bytes = (uint64_t)((e = getenv("MKT_BLOCK_MB")) ? atoi(e) : 256) << 20;
+    p.tiles = MKT_TILES_AUTO;
+    if ((e = getenv("MKT_TILES"))) p.tiles = !strcmp(e, "small") ? MKT_TILES_SMALL : !strcmp(e, "fast") ? MKT_TILES_FAST : MKT_TILES_AUTO;
+
+    mkt_ctx* ctx = nullptr;
+    int rc = mkt_create(&p, &ctx);
+    if (rc != MKT_OK) {
+        std::cerr << "Error: GPU context: " << mkt_strerror(rc) << ": " << mkt_last_error(nullptr) << "\n";
+        return 20;
+    }
+    std::vector<char> buf((size_t)64 << 20);
+    auto pump = [&]() -> bool {
+        mkt_out o;
+        if (mkt_drain(ctx, &o) != MKT_OK) return false;
+        if (o.pairs_len && fwrite(o.pairs, 1, o.pairs_len, stdout) != o.pairs_len) return false;
+        if (fsam && o.sam_len && fwrite(o.sam, 1, o.sam_len, fsam) != o.sam_len) return false;
+        return true;
+    };
+    for (;;) {
+        size_t got = fread(buf.data(), 1, buf.size(), fin);
+        int last = got < buf.size();
+        rc = mkt_submit(ctx, buf.data(), got, last);
+        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
+        if (!pump()) { std::cerr << "Error: write output failed!\n"; return 22; }
+        if (last) break;
+    }
+    fclose(fin);
+    mkt_stats st;
+    rc = mkt_finish(ctx, 1, 0, 0, &st);
+    if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
+    if (!pump()) { std::cerr << "Error: write output failed!\n"; return 22; }
+    fflush(stdout);
+    if (fsam) fclose(fsam);
+
+    std::ofstream flog((base + "2pairs.log").c_str());     // sam2pairs.cpp:195-219
+    if (flog.fail()) { std::cerr << "Error: write log file failed!\n"; return 10; }
+    char log[512];
+    mkt_format_log(&st, log, sizeof log);
+    flog << log;
+    flog.close();
+    mkt_destroy(ctx);
+    return 0;
+}

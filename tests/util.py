@@ -1,0 +1,143 @@
+"""Shared helpers for the test-suite: oracle binding (CHECKER only), reference runner, generators."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+ORACLE_EXE = os.path.join(ROOT, "oracle", "_build", "sam2pairs_oracle")
+REF_EXE = os.path.join(ROOT, "oracle", "_ref", "sam2pairs.ref")
+EMUL_SO = os.path.join(ROOT, "tests", "host", "_build", "libmkt_emul.so")
+SYNTH_EXE = os.path.join(ROOT, "tools", "_build", "synth_sam")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+MODES = {"flash": 0, "unc": 1}
+
+
+def ensure_built():
+    """Builds the CPU-side test tools (oracle, emulation, generator) if missing."""
+    need = [ORACLE_SO, ORACLE_EXE, EMUL_SO, SYNTH_EXE]
+    if all(os.path.exists(p) for p in need):
+        return
+    import sys
+    sys.path.insert(0, ROOT)
+    from microcket_amd import build
+    build.build_oracle()
+    build.build_test_tools()
+
+
+class _OP(C.Structure):
+    _fields_ = [("mode", C.c_int), ("threads", C.c_int), ("ratio", C.c_float), ("min_mapq", C.c_int), ("write_sam", C.c_int)]
+
+
+class _OB(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("n", C.c_size_t), ("cap", C.c_size_t)]
+
+
+class OStats(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in "lowMap manyHits unpaired selfCircle trans cis10K cis1K cis0 selfCircle_all".split()] + \
+               [(k, C.c_uint64) for k in "lines records groups pairs".split()]
+
+
+_oracle = None
+
+
+def oracle_run(text: bytes, mode, threads=4, ratio=0.5, mapq=10, sam=True):
+    """The CPU restatement (oracle/): returns (pairs, sam, log, stats). Input order output."""
+    global _oracle
+    ensure_built()
+    if _oracle is None:
+        _oracle = C.CDLL(ORACLE_SO)
+    if isinstance(mode, str):
+        mode = MODES[mode]
+    p = _OP(mode, threads, ratio, mapq, 1 if sam else 0)
+    a, b, st = _OB(), _OB(), OStats()
+    rc = _oracle.orc_run(text, C.c_size_t(len(text)), C.byref(p), C.byref(a), C.byref(b), C.byref(st))
+    assert rc == 0
+    pairs = C.string_at(a.p, a.n) if a.n else b""
+    s = C.string_at(b.p, b.n) if b.n else b""
+    log = C.create_string_buffer(512)
+    _oracle.orc_format_log(C.byref(st), log, 512)
+    _oracle.orc_buf_free(C.byref(a))
+    _oracle.orc_buf_free(C.byref(b))
+    return pairs, s, log.value, st
+
+
+def have_ref():
+    return os.path.exists(REF_EXE)
+
+
+def _run_cli(exe, text, mode, threads, ratio, mapq, sam, env=None):
+    with tempfile.TemporaryDirectory(prefix="mkt_") as d:
+        inp = os.path.join(d, "in.sam")
+        with open(inp, "wb") as f:
+            f.write(text)
+        prefix = os.path.join(d, "out")
+        e = dict(os.environ)
+        if env:
+            e.update(env)
+        p = subprocess.run([exe, inp, mode, prefix, str(threads), repr(ratio), str(mapq), "yes" if sam else "no"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+        log = b""
+        lp = f"{prefix}.{mode}2pairs.log"
+        if os.path.exists(lp):
+            log = open(lp, "rb").read()
+        s = b""
+        sp = f"{prefix}.{mode}.sam"
+        if os.path.exists(sp):
+            s = open(sp, "rb").read()
+        return p.returncode, p.stdout, s, log, p.stderr
+
+
+def ref_run(text, mode, threads=4, ratio=0.5, mapq=10, sam=True):
+    """The reference itself (oracle/_ref, compiled from /root/reference by oracle/Makefile)."""
+    return _run_cli(REF_EXE, text, mode, threads, ratio, mapq, sam)
+
+
+def cli_run(exe, text, mode, threads=4, ratio=0.5, mapq=10, sam=True, env=None):
+    return _run_cli(exe, text, mode, threads, ratio, mapq, sam, env)
+
+
+def canon(b: bytes) -> bytes:
+    """LANG=C sort of lines (the driver's canonical form, microcket:480)."""
+    lines = b.split(b"\n")
+    if lines and lines[-1] == b"":
+        lines.pop()
+    lines.sort()
+    return b"\n".join(lines) + (b"\n" if lines else b"")
+
+
+def sha(b: bytes) -> str:
+    return hashlib.sha256(b).hexdigest()
+
+
+def synth(profile, seed, n_groups, read_len=150, genome="hg38", lanes=1, tail=1, first=0) -> bytes:
+    ensure_built()
+    return subprocess.run([SYNTH_EXE, profile, str(seed), str(n_groups), str(read_len), genome, str(lanes), str(tail), str(first)],
+                          stdout=subprocess.PIPE, check=True).stdout
+
+
+# ---- host emulation of the tile algorithm (TEST TOOL; see tests/host/tile_emul.cpp)
+_emul = None
+
+
+def emul_run(text, mode, threads=4, ratio=0.5, mapq=10, sam=True, cfg=0, block=0):
+    global _emul
+    ensure_built()
+    if _emul is None:
+        _emul = C.CDLL(EMUL_SO)
+    if isinstance(mode, str):
+        mode = MODES[mode]
+    op, osam = C.c_void_p(), C.c_void_p()
+    npairs, nsam = C.c_size_t(), C.c_size_t()
+    log = C.create_string_buffer(256)
+    st = (C.c_uint64 * 4)()
+    _emul.emul_run(text, C.c_size_t(len(text)), mode, C.c_float(ratio), mapq, 1 if sam else 0, threads, cfg, C.c_size_t(block),
+                   C.byref(op), C.byref(npairs), C.byref(osam), C.byref(nsam), log, st)
+    pairs = C.string_at(op, npairs.value)
+    s = C.string_at(osam, nsam.value)
+    _emul.emul_free(op)
+    _emul.emul_free(osam)
+    return pairs, s, log.value, {"groups": st[0], "pairs": st[1], "err": st[2], "blocks": st[3]}
