@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- read-pairs/s through the sam2pairs hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[1] -- 100 M synthetic 150 bp PE read pairs with
+hg38 chromosome names (seeded generator), unstitched mode, sam=no (the driver's -x),
+~92 GB of SAM text resident in HBM per GPU before the timed region starts.  One STEP = one pass
+of the hot path over the whole resident data set (all blocks).  N > 1: every rank holds its own
+100 M-pair shard (weak scaling; shard r = groups [r*P, (r+1)*P) of one seeded data set); the only
+exchange is the group-count all_gather + 8-counter all_reduce at the end (quirks Q1/Q2).
+
+`value` = pairs processed by all ranks / wall time of K steps (max over ranks), inputs resident.
+`roofline`: the fused tile kernel (k_tiles), algorithmic bytes (SAM bytes in + .pairs bytes out)
+per launch over its HIP-event launch duration, against 8 TB/s HBM.
+`cpu_baseline`: the reference itself (oracle/_ref/sam2pairs.ref, built from /root/reference by
+oracle/Makefile) timed on this host on a bounded sample of the same data (first blocks).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(ctx, ds, sample_groups, threads):
+    """Times the reference (or, if absent, the C restatement) on the first blocks of the data set."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "sam2pairs.ref")
+    port = os.path.join(ROOT, "oracle", "_build", "sam2pairs_oracle")
+    exe, kind = (ref, "reference") if os.path.exists(ref) else (port, "port")
+    if not os.path.exists(exe):
+        return None
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    d = tempfile.mkdtemp(prefix="mkt_bench_", dir=tmpdir)
+    path = os.path.join(d, "sample.sam")
+    groups = 0
+    nbytes = 0
+    try:
+        with open(path, "wb") as f:
+            for (p, n, g) in ds.blocks:
+                f.write(ctx.copy_to_host(p, n))
+                groups += g
+                nbytes += n
+                if groups >= sample_groups:
+                    break
+        t0 = time.time()
+        with open(os.devnull, "wb") as null:
+            rc = subprocess.run([exe, path, "unc", os.path.join(d, "out"), str(threads), "0.5", "10", "no"], stdout=null,
+                                stderr=subprocess.PIPE).returncode
+        dt = time.time() - t0
+        if rc != 0:
+            return None
+        return {"value": groups / dt, "unit": "read-pairs/s", "cores": threads if kind == "reference" else 1, "kind": kind,
+                "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input, sam=no, thread={threads}, {dt:.1f} s",
+                "host_cpus": os.cpu_count()}
+    finally:
+        try:
+            for fn in os.listdir(d):
+                os.unlink(os.path.join(d, fn))
+            os.rmdir(d)
+        except OSError:
+            pass
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=int(os.environ.get("MKT_BENCH_PAIRS", 100_000_000)), help="read pairs per GPU")
+    ap.add_argument("--block-groups", type=int, default=1 << 19)
+    ap.add_argument("--sam", default="no", choices=["no", "yes"])
+    ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    dist = None
+    torch = None
+    if world > 1:
+        import torch  # noqa: F811
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    else:
+        try:
+            import torch  # noqa: F811  (only for torch.cuda.synchronize around the timed region)
+        except Exception:
+            torch = None
+
+    import microcket_amd as m
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    def dev_sync():
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    profile = 0 if args.mode == "unc" else 1
+    seed = 20260104 + 1  # seeds 20260104 + config index
+    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=m.TILES_FAST)
+    t0 = time.time()
+    ds = ctx.dataset(seed, profile, args.pairs, args.block_groups, first_group=rank * args.pairs, genome=0, read_len=150, lanes=1,
+                     tail_group=(rank == world - 1))
+    log(f"[rank {rank}] data set: {ds.total_groups} pairs, {ds.total_bytes / 1e9:.2f} GB in {ds.n_blocks} blocks, generated in {time.time() - t0:.1f} s")
+
+    def one_pass():
+        for (p, n, _g) in ds.blocks:
+            ctx.submit_device(p, n)
+
+    for _ in range(max(args.warmup, 0)):
+        one_pass()
+    ctx.sync()
+    ctx.reset()
+    ctx.reset_timing()
+
+    # ---- timed region: exactly K steps (each one pass over the resident data set)
+    dev_sync(); barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    ctx.sync()
+    dev_sync(); barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tmg = ctx.timing()
+    tm_ms, tm_launch, tm_bytes = tmg.tile_kernel_ms, tmg.tile_launches, tmg.tile_bytes
+
+    # ---- one more (untimed) pass for the end-of-input bookkeeping and the counters of ONE pass
+    ctx.reset()
+    one_pass()
+    my_groups = ctx.group_count()
+    if dist is not None:
+        gl = [None] * world
+        dist.all_gather_object(gl, my_groups)
+        offset = sum(gl[:rank])
+        total = sum(gl)
+        last_nonempty = max(i for i, g in enumerate(gl) if g > 0)
+        st = ctx.finish(drop_last=(rank == last_nonempty), group_offset=offset, total_groups=total)
+        cnt = torch.tensor([st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes],
+                           dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt)
+        counters = [int(x) for x in cnt.tolist()]
+    else:
+        st = ctx.finish(True)
+        counters = [st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes]
+
+    pairs_per_step = ds.total_groups
+    out_bytes_step = st.pair_bytes + (st.sam_bytes if args.sam == "yes" else 0)
+    algo_bytes_step = ds.total_bytes + out_bytes_step
+    total_pairs = pairs_per_step * args.steps * world
+    value = total_pairs / elapsed
+    result = None
+    if rank == 0:
+        achieved = (algo_bytes_step * args.steps) / (tm_ms / 1e3) / 1e9 if tm_ms > 0 else 0.0
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(ctx, ds, args.cpu_sample_pairs, 8)
+        result = {
+            "metric": "read-pairs/sec through sam2pairs (150 bp PE, hg38 names, SAM text resident in HBM)",
+            "value": value,
+            "unit": "read-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: {args.pairs} synthetic 150 bp PE read pairs per GPU, hg38 chromosome names, {args.mode} mode, sam={args.sam}, "
+                            f"seed {seed}, one step = one pass over the whole resident data set",
+                "pairs_per_gpu": ds.total_groups,
+                "sam_bytes_per_gpu": ds.total_bytes,
+                "bytes_per_pair_in": ds.total_bytes / ds.total_groups,
+                "bytes_per_pair_out": out_bytes_step / ds.total_groups,
+                "block_groups": args.block_groups,
+                "blocks": ds.n_blocks,
+                "parallelism": f"shard{world}: independent read-group shards, no data-path collective",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_tiles (fused scan/parse/classify/format)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launches": tm_launch,
+                "avg_launch_ms": tm_ms / tm_launch if tm_launch else None,
+                "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / tm_launch if tm_launch else None,
+            },
+            "cpu_baseline": cpu,
+            "counters": dict(zip(["lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0", "pairs", "pair_bytes"], counters)),
+        }
+        if cpu:
+            result["speedup_vs_cpu_baseline"] = value / cpu["value"]
+    ds.close()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -55,7 +55,8 @@ typedef struct mkt_params {
     int32_t device;            /* HIP device ordinal */
     uint64_t block_bytes;      /* bytes of SAM text per kernel pass, 0 = default (256 MiB); < 1 GiB */
     int32_t tiles;             /* MKT_TILES_* */
-    int32_t reserved;
+    int32_t ordered;           /* 1: outputs in input order (deterministic bytes); 0 (default): any order, like the
+                                * reference, whose worker threads fwrite concurrently (sam2pairs.cpp:154,175) */
 } mkt_params;
 
 /* The 8 counters of <prefix>.<mode>2pairs.log in file order (sam2pairs.cpp:211-218), plus totals. */
@@ -119,6 +120,10 @@ int mkt_finish(mkt_ctx* ctx, int drop_last, uint64_t group_offset, uint64_t tota
 /* formats the 8-line log exactly as sam2pairs.cpp:211-218; returns bytes written */
 int mkt_format_log(const mkt_stats* st, char* out, size_t cap);
 
+/* forget everything seen so far (counters, pending group, outputs) but keep the device buffers:
+ * the context is ready for a new input stream */
+int mkt_reset(mkt_ctx* ctx);
+
 int mkt_get_timing(const mkt_ctx* ctx, mkt_timing* t);
 int mkt_reset_timing(mkt_ctx* ctx);
 
@@ -130,6 +135,20 @@ int mkt_synth_device(mkt_ctx* ctx, uint64_t seed, int profile, int genome, int r
                      uint64_t first_group, uint64_t n_groups, int tail_group,
                      const void** d_text, size_t* n_bytes);
 int mkt_copy_to_host(mkt_ctx* ctx, const void* d_src, void* dst, size_t n);
+
+/* A whole synthetic data set resident in HBM, cut into group-aligned blocks (bench.py's workload:
+ * 100 M read pairs = ~92 GB of SAM text on one MI355X).  Blocks are 16-byte aligned. */
+typedef struct mkt_dataset mkt_dataset;
+int mkt_dataset_create(mkt_ctx* ctx, uint64_t seed, int profile, int genome, int read_len, int lanes,
+                       uint64_t first_group, uint64_t n_groups, uint64_t groups_per_block, int tail_group,
+                       mkt_dataset** out);
+int mkt_dataset_info(const mkt_dataset* ds, uint64_t* n_blocks, uint64_t* total_bytes, uint64_t* total_groups);
+int mkt_dataset_block(const mkt_dataset* ds, uint64_t i, const void** d_text, size_t* n_bytes, uint64_t* n_groups);
+void mkt_dataset_destroy(mkt_dataset* ds);
+
+/* surviving QNAME groups seen so far (synchronises the context's stream); sharded runs exchange
+ * these counts before mkt_finish */
+int mkt_group_count(mkt_ctx* ctx, uint64_t* groups);
 
 #ifdef __cplusplus
 }

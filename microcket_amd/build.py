@@ -48,6 +48,15 @@ def build_lib(force=False):
     return LIB
 
 
+def build_stamps_lib():
+    """Diagnostic build with per-phase shader-clock stamps in k_tiles (tools/phase_shares.py)."""
+    out = os.path.join(HERE, "libmkt_hip_stamps.so")
+    srcs = [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_capi.cpp")]
+    _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-DMKT_STAMPS", "-Wno-unused-function",
+          "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", out])
+    return out
+
+
 def build_exe(force=False):
     src = os.path.join(CSRC, "sam2pairs_main.cpp")
     if force or _newer(EXE, [src, LIB, os.path.join(ROOT, "include", "mkt.h")]):

@@ -10,6 +10,7 @@ EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
     "mkt_submit", "mkt_drain", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
+    "mkt_reset", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
 ]
 
 
@@ -20,7 +21,7 @@ class MktError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("mode", C.c_int32), ("min_mapped_ratio", C.c_float), ("min_mapq", C.c_int32), ("write_sam", C.c_int32),
                 ("ref_threads", C.c_int32), ("device", C.c_int32), ("block_bytes", C.c_uint64), ("tiles", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("ordered", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -41,7 +42,8 @@ class Timing(C.Structure):
 
 
 def lib_path():
-    return os.path.join(HERE, "libmkt_hip.so")
+    # MKT_LIB selects a diagnostic build (e.g. the phase-stamp build); never needed in production
+    return os.environ.get("MKT_LIB") or os.path.join(HERE, "libmkt_hip.so")
 
 
 def exe_path():
@@ -78,6 +80,14 @@ def load_library():
     L.mkt_synth_device.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.mkt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mkt_dataset_create.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                     C.POINTER(C.c_void_p)]
+    L.mkt_dataset_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mkt_dataset_block.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    L.mkt_dataset_destroy.argtypes = [C.c_void_p]
+    L.mkt_dataset_destroy.restype = None
+    L.mkt_reset.argtypes = [C.c_void_p]
+    L.mkt_group_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -89,11 +99,12 @@ def device_count():
 class Context:
     """One GPU context = one input stream (mirrors one bin/sam2pairs process of the reference)."""
 
-    def __init__(self, mode, ratio=0.5, min_mapq=10, write_sam=True, ref_threads=4, device=0, block_bytes=0, tiles=TILES_AUTO):
+    def __init__(self, mode, ratio=0.5, min_mapq=10, write_sam=True, ref_threads=4, device=0, block_bytes=0, tiles=TILES_AUTO,
+                 ordered=False):
         self.L = load_library()
         if isinstance(mode, str):
             mode = {"flash": MODE_FLASH, "unc": MODE_UNC}[mode]
-        self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 0)
+        self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 1 if ordered else 0)
         self.h = C.c_void_p()
         rc = self.L.mkt_create(C.byref(self.params), C.byref(self.h))
         if rc != 0:
@@ -184,6 +195,17 @@ class Context:
         self._chk(self.L.mkt_copy_to_host(self.h, C.c_void_p(d_ptr), buf, n), "mkt_copy_to_host")
         return buf.raw[:n]
 
+    def reset(self):
+        self._chk(self.L.mkt_reset(self.h), "mkt_reset")
+
+    def group_count(self):
+        g = C.c_uint64()
+        self._chk(self.L.mkt_group_count(self.h, C.byref(g)), "mkt_group_count")
+        return g.value
+
+    def dataset(self, seed, profile, n_groups, groups_per_block, first_group=0, genome=0, read_len=150, lanes=1, tail_group=False):
+        return Dataset(self, seed, profile, n_groups, groups_per_block, first_group, genome, read_len, lanes, tail_group)
+
     def timing(self):
         t = Timing()
         self._chk(self.L.mkt_get_timing(self.h, C.byref(t)), "mkt_get_timing")
@@ -191,6 +213,29 @@ class Context:
 
     def reset_timing(self):
         self._chk(self.L.mkt_reset_timing(self.h), "mkt_reset_timing")
+
+
+class Dataset:
+    """Synthetic SAM resident in HBM, cut into group-aligned blocks (see mkt_dataset_create)."""
+
+    def __init__(self, ctx, seed, profile, n_groups, groups_per_block, first_group, genome, read_len, lanes, tail_group):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+        ctx._chk(ctx.L.mkt_dataset_create(ctx.h, seed, profile, genome, read_len, lanes, first_group, n_groups, groups_per_block,
+                                          1 if tail_group else 0, C.byref(self.h)), "mkt_dataset_create")
+        nb, tb, tg = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ctx.L.mkt_dataset_info(self.h, C.byref(nb), C.byref(tb), C.byref(tg))
+        self.n_blocks, self.total_bytes, self.total_groups = nb.value, tb.value, tg.value
+        self.blocks = []
+        for i in range(self.n_blocks):
+            p, n, g = C.c_void_p(), C.c_size_t(), C.c_uint64()
+            ctx.L.mkt_dataset_block(self.h, i, C.byref(p), C.byref(n), C.byref(g))
+            self.blocks.append((p.value, n.value, g.value))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mkt_dataset_destroy(self.h)
+            self.h = C.c_void_p()
 
 
 def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes", env=None, exe=None):

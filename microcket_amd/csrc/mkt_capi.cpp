@@ -47,6 +47,7 @@ struct mkt_ctx {
     // synth
     char* d_syn = nullptr; size_t syn_cap = 0;
     uint64_t* d_syn_sizes = nullptr; size_t syn_sizes_cap = 0;
+    unsigned long long* d_stamps = nullptr;   // diagnostic builds (MKT_STAMPS) only
     std::string err;
 };
 
@@ -90,9 +91,12 @@ int mkt_device_count(void) {
     return n;
 }
 
-static size_t ws_bytes_for(uint32_t ntiles) {
-    return (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast)) + 256 + sizeof(BlockResult);
+// workspace of one block: descA | descB | descC | tile_last | tile_groups | ticket (256 B) | BlockResult
+static size_t ws_tiles_bytes(uint32_t ntiles) {
+    size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + sizeof(uint32_t));
+    return (b + 15) & ~(size_t)15;
 }
+static size_t ws_bytes_for(uint32_t ntiles) { return ws_tiles_bytes(ntiles) + 256 + sizeof(BlockResult); }
 static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
     size_t need = ws_bytes_for(ntiles);
     if (need <= c->ws_cap) return MKT_OK;
@@ -186,12 +190,19 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.descB = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.descC = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.tile_last = (TileLast*)w; w += (size_t)ntiles * sizeof(TileLast);
+    a.tile_groups = (uint32_t*)w;
+    w = c->d_ws + ws_tiles_bytes(ntiles);
     a.ticket = (uint32_t*)w; w += 256;
     a.res = (BlockResult*)w;
+    a.ordered = c->p.ordered ? 1 : 0;
     a.run = c->d_run;
     a.out.pairs = c->d_pairs; a.out.pairs_cap = c->pairs_cap;
     a.out.sam = c->d_sam; a.out.sam_cap = c->P.write_sam ? c->sam_cap : 0;
     a.out.sc = c->d_sc; a.out.sc_cap = c->sc_cap;
+#if defined(MKT_STAMPS)
+    if (!c->d_stamps) { HIPCHK(c, hipMalloc((void**)&c->d_stamps, 16 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_stamps, 0, 16 * sizeof(unsigned long long))); }
+    a.stamps = c->d_stamps;
+#endif
     HIPCHK(c, hipMemsetAsync(c->d_ws, 0, ws_bytes_for(ntiles), c->stream));
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
@@ -260,16 +271,22 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     if (pb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data(), c->d_pairs, pb, hipMemcpyDeviceToHost, c->stream));
     if (sb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + pb, c->d_sam, sb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const char* hp = (const char*)c->h_stage.data();
     if (r.last.valid) {
-        // the previous newest group is now final: release its bytes, hold back the new newest group's
+        // the previous newest group is now final: release its bytes; hold back the new newest group's
+        // (its bytes sit at [pair_off, +pair_bytes) / [sam_off, +sam_bytes) of this block's outputs)
         c->out_pairs.insert(c->out_pairs.end(), c->tail_pairs.begin(), c->tail_pairs.end());
         c->out_sam.insert(c->out_sam.end(), c->tail_sam.begin(), c->tail_sam.end());
-        size_t tp = r.last.pair_bytes, ts = c->P.write_sam ? r.last.sam_bytes : 0;
-        const char* hp = (const char*)c->h_stage.data();
-        c->out_pairs.insert(c->out_pairs.end(), hp, hp + (pb - tp));
-        c->tail_pairs.assign(hp + (pb - tp), hp + pb);
-        c->out_sam.insert(c->out_sam.end(), hp + pb, hp + pb + (sb - ts));
-        c->tail_sam.assign(hp + pb + (sb - ts), hp + pb + sb);
+        const size_t tp = r.last.pair_bytes, po = r.last.pair_off;
+        const size_t ts = c->P.write_sam ? r.last.sam_bytes : 0, so = r.last.sam_off;
+        c->out_pairs.insert(c->out_pairs.end(), hp, hp + po);
+        c->out_pairs.insert(c->out_pairs.end(), hp + po + tp, hp + pb);
+        c->tail_pairs.assign(hp + po, hp + po + tp);
+        if (sb) {
+            c->out_sam.insert(c->out_sam.end(), hp + pb, hp + pb + so);
+            c->out_sam.insert(c->out_sam.end(), hp + pb + so + ts, hp + pb + sb);
+            c->tail_sam.assign(hp + pb + so, hp + pb + so + ts);
+        } else c->tail_sam.clear();
     }
     return MKT_OK;
 }
@@ -351,7 +368,7 @@ int mkt_fetch_last_block(mkt_ctx* c, char* pairs, size_t pairs_cap, size_t* pair
     // the last folded result is not kept per block; re-read it from the device workspace
     BlockResult r;
     const uint32_t ntiles = num_tiles((uint32_t)c->last_n, tile_bytes(c->cfg));
-    const uint8_t* w = c->d_ws + (size_t)ntiles * (3 * 8 + sizeof(TileLast)) + 256;
+    const uint8_t* w = c->d_ws + ws_tiles_bytes(ntiles) + 256;
     HIPCHK(c, hipMemcpy(&r, w, sizeof r, hipMemcpyDeviceToHost));
     if (pairs_len) *pairs_len = (size_t)r.pair_bytes;
     if (sam_len) *sam_len = c->P.write_sam ? (size_t)r.sam_bytes : 0;
@@ -389,6 +406,22 @@ int mkt_finish(mkt_ctx* c, int drop_last, uint64_t group_offset, uint64_t total_
         c->tail_pairs.clear(); c->tail_sam.clear();
         c->finished = true;
     }
+    return MKT_OK;
+}
+
+int mkt_reset(mkt_ctx* c) {
+    if (!c) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fold_timing(c);
+    HIPCHK(c, hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->acc = RunAccum();
+    c->res_used = c->res_folded = 0;
+    c->h_len = 0;
+    c->out_pairs.clear(); c->out_sam.clear(); c->tail_pairs.clear(); c->tail_sam.clear();
+    c->input_done = c->finished = false;
+    c->bytes_in = 0; c->blocks = 0;
     return MKT_OK;
 }
 
@@ -442,6 +475,101 @@ int mkt_synth_device(mkt_ctx* c, uint64_t seed, int profile, int genome, int rea
     *n_bytes = (size_t)total + tail;
     return MKT_OK;
 }
+
+struct mkt_dataset {
+    mkt_ctx* ctx;
+    char* arena = nullptr;
+    std::vector<uint64_t> off, len, groups;
+    uint64_t total_bytes = 0, total_groups = 0;
+};
+
+int mkt_dataset_create(mkt_ctx* c, uint64_t seed, int profile, int genome, int read_len, int lanes, uint64_t first_group,
+                       uint64_t n_groups, uint64_t gpb, int tail_group, mkt_dataset** out) {
+    if (!c || !out || gpb == 0) return MKT_E_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    SynParams sp;
+    sp.seed = seed; sp.profile = profile; sp.genome = genome; sp.read_len = read_len; sp.lanes = lanes;
+    if (c->syn_sizes_cap < gpb + 2) {
+        if (c->d_syn_sizes) HIPCHK(c, hipFree(c->d_syn_sizes));
+        c->d_syn_sizes = nullptr;
+        HIPCHK(c, hipMalloc((void**)&c->d_syn_sizes, (gpb + 2) * sizeof(uint64_t)));
+        c->syn_sizes_cap = gpb + 2;
+    }
+    mkt_dataset* ds = new mkt_dataset();
+    ds->ctx = c;
+    const uint64_t nb = (n_groups + gpb - 1) / gpb;
+    const size_t tail = tail_group ? synth_tail_bytes(sp) : 0;
+    uint64_t* d_total = c->d_syn_sizes + gpb;
+    uint64_t cursor = 0;
+    for (uint64_t b = 0; b < nb; ++b) {          // pass 1: block sizes
+        const uint64_t g0 = b * gpb, g = (g0 + gpb <= n_groups) ? gpb : n_groups - g0;
+        HIPCHK(c, launch_synth_sizes(sp, first_group + g0, g, c->d_syn_sizes, c->stream));
+        HIPCHK(c, launch_exscan(c->d_syn_sizes, g, d_total, c->stream));
+        uint64_t total = 0;
+        HIPCHK(c, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (b + 1 == nb) total += tail;
+        if (total >= ((uint64_t)1 << 30)) { delete ds; return fail(c, MKT_E_ARG, "block %llu would hold %llu bytes (>= 1 GiB): lower groups_per_block", (unsigned long long)b, (unsigned long long)total); }
+        ds->off.push_back(cursor); ds->len.push_back(total); ds->groups.push_back(g + ((b + 1 == nb && tail_group) ? 1 : 0));
+        cursor += (total + 15) & ~(uint64_t)15;
+    }
+    ds->total_bytes = 0;
+    for (uint64_t l : ds->len) ds->total_bytes += l;
+    ds->total_groups = n_groups + (tail_group ? 1 : 0);
+    hipError_t e = hipMalloc((void**)&ds->arena, cursor + 64);
+    if (e != hipSuccess) { delete ds; return fail(c, MKT_E_NOMEM, "hipMalloc of %llu bytes for the data set failed: %s", (unsigned long long)cursor, hipGetErrorString(e)); }
+    for (uint64_t b = 0; b < nb; ++b) {          // pass 2: bytes
+        const uint64_t g0 = b * gpb, g = (g0 + gpb <= n_groups) ? gpb : n_groups - g0;
+        HIPCHK(c, launch_synth_sizes(sp, first_group + g0, g, c->d_syn_sizes, c->stream));
+        HIPCHK(c, launch_exscan(c->d_syn_sizes, g, d_total, c->stream));
+        HIPCHK(c, launch_synth_write(sp, first_group + g0, g, c->d_syn_sizes, ds->arena + ds->off[b], c->stream));
+        if (b + 1 == nb && tail) HIPCHK(c, launch_synth_tail(sp, ds->arena + ds->off[b] + ds->len[b] - tail, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    *out = ds;
+    return MKT_OK;
+}
+int mkt_dataset_info(const mkt_dataset* ds, uint64_t* n_blocks, uint64_t* total_bytes, uint64_t* total_groups) {
+    if (!ds) return MKT_E_ARG;
+    if (n_blocks) *n_blocks = ds->off.size();
+    if (total_bytes) *total_bytes = ds->total_bytes;
+    if (total_groups) *total_groups = ds->total_groups;
+    return MKT_OK;
+}
+int mkt_dataset_block(const mkt_dataset* ds, uint64_t i, const void** d_text, size_t* n_bytes, uint64_t* n_groups) {
+    if (!ds || i >= ds->off.size()) return MKT_E_ARG;
+    if (d_text) *d_text = ds->arena + ds->off[i];
+    if (n_bytes) *n_bytes = (size_t)ds->len[i];
+    if (n_groups) *n_groups = ds->groups[i];
+    return MKT_OK;
+}
+void mkt_dataset_destroy(mkt_dataset* ds) {
+    if (!ds) return;
+    if (ds->arena) { hipSetDevice(ds->ctx->p.device); hipFree(ds->arena); }
+    delete ds;
+}
+
+int mkt_group_count(mkt_ctx* c, uint64_t* groups) {
+    if (!c || !groups) return MKT_E_ARG;
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    *groups = c->acc.groups;
+    return MKT_OK;
+}
+
+#if defined(MKT_STAMPS)
+// diagnostic build only: per-phase shader-clock sums of k_tiles (see STAMP in mkt_kernels.hip)
+int mkt_debug_stamps(mkt_ctx* c, unsigned long long* out16) {
+    if (!c || !out16) return MKT_E_ARG;
+    memset(out16, 0, 16 * sizeof(unsigned long long));
+    if (!c->d_stamps) return MKT_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out16, c->d_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_stamps, 0, 16 * sizeof(unsigned long long)));
+    return MKT_OK;
+}
+#endif
 
 int mkt_copy_to_host(mkt_ctx* c, const void* d_src, void* dst, size_t n) {
     if (!c || !d_src || !dst) return MKT_E_ARG;

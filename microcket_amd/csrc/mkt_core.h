@@ -38,17 +38,51 @@ struct Params {
     int write_sam;
 };
 
-// Block text in global memory plus the on-chip window [w0, w0 + wlen) of it.
+// Block text in global memory plus the on-chip window [w0, w0 + wlen) of it.  The window copy is
+// padded with >= 16 zero bytes; nlm / wsm are bitmaps over the window (bit r <-> byte w0 + r:
+// newline / whitespace), zero beyond wlen and padded by two zero words.
 struct TextView {
     const uint8_t* g;     // block base
     uint32_t n;           // block bytes
-    const uint8_t* win;   // window copy (LDS on the GPU)
+    const uint8_t* win;   // window copy (LDS on the GPU), 16-byte aligned
     uint32_t w0, wlen;
+    const uint64_t* nlm;
+    const uint64_t* wsm;
     MKT_HD uint8_t at(uint32_t off) const {
         uint32_t r = off - w0;
         return r < wlen ? win[r] : g[off];
     }
+    MKT_HD bool inside(uint32_t off, uint32_t len) const {      // [off, off+len) lies in the window
+        uint32_t r = off - w0;
+        return r < wlen && len <= wlen - r;
+    }
 };
+
+// four window bytes starting at window-relative byte r (little endian), from aligned dwords
+MKT_HD uint32_t win_load4(const TextView& tv, uint32_t r) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tv.win);
+    const uint32_t i = r >> 2;
+    const uint32_t a = w[i], b = w[i + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(b, a, r & 3u);
+#else
+    const uint32_t sh = (r & 3u) * 8u;
+    return sh ? ((a >> sh) | (b << (32u - sh))) : a;
+#endif
+}
+// 64 bitmap bits starting at bit r
+MKT_HD uint64_t bits64(const uint64_t* m, uint32_t r) {
+    const uint32_t w = r >> 6, sh = r & 63u;
+    const uint64_t lo = m[w];
+    return sh ? ((lo >> sh) | (m[w + 1] << (64u - sh))) : lo;
+}
+MKT_HD uint32_t ctz64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__ffsll((long long)v) - 1u;
+#else
+    return (uint32_t)__builtin_ctzll(v);
+#endif
+}
 
 MKT_HD bool is_ws(uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); }   // classic-locale isspace
 
@@ -64,22 +98,62 @@ struct Rec {
     bool survive;              // six well-formed tokens and passes the FLAG/MAPQ filter
 };
 
-// Parses the record starting at `off`.  Stops after the sixth token; never reads at or past the
-// line's '\n'.  Token rules follow `ss >> a >> b ...` (whitespace-separated, leading blanks skipped).
-// A record with fewer than six tokens, a non-decimal FLAG/POS/MAPQ or a header line ('@') does
-// not survive (the reference's behaviour on such lines is undefined / input-order dependent).
-MKT_HD Rec parse_record(const TextView& tv, uint32_t off, const Params& P) {
-    Rec r;
+// cigar2segment (pairutil.h:63-126) as a byte-at-a-time state machine.
+struct CigarWalk {
+    int32_t index, value, cur, lastRight;
+    bool bad;
+    MKT_HD void begin(Rec& r) {
+        index = 0; value = 0; cur = (int32_t)r.pos; lastRight = 0; bad = false;
+        r.left0 = (int32_t)r.pos;
+    }
+    // c: CIGAR byte; lastChar: it is the last byte of the token (pairutil.h:88)
+    MKT_HD void step(Rec& r, uint8_t c, bool lastChar) {
+        if (bad) return;
+        if (c >= '0' && c <= '9') { value = value * 10 + (int32_t)(c - '0'); return; }
+        if (c == 'H' || c == 'S') {
+            if (lastChar) r.rclip = value;
+            else if (index == 0) r.lclip = value;
+            else bad = true;
+        } else if (c == 'M' || c == 'D') {
+            if (c == 'M') r.mappable += value;
+            cur += value;
+            lastRight = cur - 1;
+            if (index == 0) r.right0 = lastRight; else if (index == 1) r.right1 = lastRight;
+        } else if (c == 'I') {
+        } else if (c == 'N') {
+            cur += value;
+            ++index;
+            lastRight = 0;
+            if (index == 1) { r.left1 = cur; r.right1 = 0; }
+        } else {
+            bad = true;
+        }
+        value = 0;
+    }
+    MKT_HD void end(Rec& r) {
+        if (!bad && lastRight != 0) { r.segCnt = index + 1; r.rightLast = lastRight; }
+    }
+};
+MKT_HD void rec_clear(Rec& r, uint32_t off) {
     r.off = off; r.qn_off = r.qn_len = r.rn_off = r.rn_len = 0;
     r.flag = r.pos = r.mapq = 0;
     r.segCnt = 0; r.lclip = r.rclip = r.mappable = 0;
     r.left0 = r.left1 = r.right0 = r.right1 = r.rightLast = 0;
     r.survive = false;
+}
+
+// Parses the record starting at `off`, anywhere in the block (generic, byte at a time).  Stops
+// after the sixth token; never reads at or past the line's '\n'.  Token rules follow
+// `ss >> a >> b ...` (whitespace-separated, leading blanks skipped).  A record with fewer than six
+// tokens, a non-decimal FLAG/POS/MAPQ or a header line ('@') does not survive (the reference's
+// behaviour on such lines is undefined / input-order dependent).
+MKT_HD Rec parse_record(const TextView& tv, uint32_t off, const Params& P) {
+    Rec r;
+    rec_clear(r, off);
     const uint32_t n = tv.n;
     uint32_t p = off;
     if (p >= n) return r;
-    bool header = tv.at(p) == '@';
-    bool ok = !header;
+    bool ok = tv.at(p) != '@';
     for (int k = 0; k < 6; ++k) {
         uint8_t c = 0;
         while (p < n) { c = tv.at(p); if (c == '\n' || !is_ws(c)) break; ++p; }
@@ -96,42 +170,17 @@ MKT_HD Rec parse_record(const TextView& tv, uint32_t off, const Params& P) {
             }
             if (v > 0xFFFFFFFFull) ok = false;
             if (k == 1) r.flag = (uint32_t)v; else if (k == 3) r.pos = (uint32_t)v; else r.mapq = (uint32_t)v;
-        } else if (k == 5) {                        // CIGAR -> segments, pairutil.h:63-126
-            int32_t index = 0, value = 0, cur = (int32_t)r.pos, lastRight = 0;
-            bool bad = false;
-            r.left0 = (int32_t)r.pos;
+        } else if (k == 5) {                        // CIGAR -> segments
+            CigarWalk cw;
+            cw.begin(r);
             while (p < n) {
                 c = tv.at(p);
                 if (c == '\n' || is_ws(c)) break;
                 ++p;
-                if (bad) continue;
-                if (c >= '0' && c <= '9') { value = value * 10 + (int32_t)(c - '0'); continue; }
-                if (c == 'H' || c == 'S') {
-                    uint8_t nx = p < n ? tv.at(p) : (uint8_t)'\n';
-                    bool lastChar = (nx == '\n' || is_ws(nx));
-                    if (lastChar) r.rclip = value;
-                    else if (index == 0) r.lclip = value;
-                    else bad = true;
-                } else if (c == 'M' || c == 'D') {
-                    if (c == 'M') r.mappable += value;
-                    cur += value;
-                    lastRight = cur - 1;
-                    if (index == 0) r.right0 = lastRight; else if (index == 1) r.right1 = lastRight;
-                } else if (c == 'I') {
-                } else if (c == 'N') {
-                    cur += value;
-                    ++index;
-                    lastRight = 0;
-                    if (index == 1) { r.left1 = cur; r.right1 = 0; }
-                } else {
-                    bad = true;
-                }
-                value = 0;
+                uint8_t nx = p < n ? tv.at(p) : (uint8_t)'\n';
+                cw.step(r, c, nx == '\n' || is_ws(nx));
             }
-            if (!bad && lastRight != 0) {
-                r.segCnt = index + 1;
-                r.rightLast = lastRight;
-            }
+            cw.end(r);
         } else {                                    // QNAME, RNAME
             while (p < n) { c = tv.at(p); if (c == '\n' || is_ws(c)) break; ++p; }
             if (k == 0) { r.qn_off = ts - off; r.qn_len = p - ts; } else { r.rn_off = ts - off; r.rn_len = p - ts; }
@@ -141,17 +190,108 @@ MKT_HD Rec parse_record(const TextView& tv, uint32_t off, const Params& P) {
     return r;
 }
 
+// unsigned decimal token of `len` bytes at window offset rr (all bytes inside the window)
+MKT_HD uint32_t win_parse_uint(const TextView& tv, uint32_t rr, uint32_t len, bool& ok) {
+    if (len > 10u) { ok = false; return 0; }
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < len; i += 4u) {
+        uint32_t w = win_load4(tv, rr + i);
+        const uint32_t m = len - i < 4u ? len - i : 4u;
+        for (uint32_t b = 0; b < m; ++b) {
+            const uint32_t d = (w & 0xFFu) - (uint32_t)'0';
+            if (d > 9u) ok = false;
+            v = v * 10u + d;
+            w >>= 8;
+        }
+    }
+    if (v > 0xFFFFFFFFull) ok = false;
+    return (uint32_t)v;
+}
+
+// Fast parser for a line that starts inside the window: token boundaries come from the
+// whitespace / newline bitmaps (the first 128 bytes of the line), field bytes from aligned dword
+// loads.  Returns PF_OK when r is exactly what parse_record would produce; PF_LONG when the six
+// fields do not end inside the line's first 128 bytes (the caller uses parse_record); PF_CUT when
+// the window ends before the sixth field does (the line sits at the very end of the window).
+enum { PF_OK = 1, PF_LONG = 0, PF_CUT = -1 };
+MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r) {
+    rec_clear(r, off);
+    const uint32_t rr = off - tv.w0;
+    if (rr >= tv.wlen) return PF_CUT;
+    const uint32_t avail = tv.wlen - rr;
+    const uint64_t nl0 = bits64(tv.nlm, rr), nl1 = bits64(tv.nlm, rr + 64u);
+    const uint64_t ws0 = bits64(tv.wsm, rr), ws1 = bits64(tv.wsm, rr + 64u);
+    const uint32_t L = nl0 ? ctz64(nl0) : (nl1 ? 64u + ctz64(nl1) : 128u);      // first '\n' (bitmaps are zero past wlen)
+    uint32_t lim = avail < 128u ? avail : 128u;
+    if (L < lim) lim = L;
+    const bool terminated = (L < 128u && lim == L) || (off + lim == tv.n);        // the line really ends at lim
+    const uint64_t m0 = lim >= 64u ? ~0ull : ((1ull << lim) - 1ull);
+    const uint64_t m1 = lim <= 64u ? 0ull : (lim >= 128u ? ~0ull : ((1ull << (lim - 64u)) - 1ull));
+    const uint64_t n0 = ~ws0 & m0, n1 = ~ws1 & m1;                                // token bytes
+    uint64_t s0 = n0 & ~(n0 << 1), s1 = n1 & ~((n1 << 1) | (n0 >> 63));           // first byte of each token
+    uint64_t e0 = n0 & ~((n0 >> 1) | (n1 << 63)), e1 = n1 & ~(n1 >> 1);           // last byte of each token
+    uint32_t ts[6], te[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 6; ++k) {
+        if (s0) { ts[k] = ctz64(s0); s0 &= s0 - 1ull; }
+        else if (s1) { ts[k] = 64u + ctz64(s1); s1 &= s1 - 1ull; }
+        else return terminated ? PF_OK : (lim == avail ? PF_CUT : PF_LONG);   // a complete line with fewer than six tokens is no record
+        if (e0) { te[k] = ctz64(e0); e0 &= e0 - 1ull; }
+        else { te[k] = 64u + ctz64(e1); e1 &= e1 - 1ull; }
+    }
+    if (te[5] + 1u == lim && !terminated) return lim == avail ? PF_CUT : PF_LONG;      // the CIGAR may continue past what we can see
+    bool ok = tv.win[rr] != '@';
+    r.qn_off = ts[0]; r.qn_len = te[0] + 1u - ts[0];
+    r.rn_off = ts[2]; r.rn_len = te[2] + 1u - ts[2];
+    r.flag = win_parse_uint(tv, rr + ts[1], te[1] + 1u - ts[1], ok);
+    r.pos = win_parse_uint(tv, rr + ts[3], te[3] + 1u - ts[3], ok);
+    r.mapq = win_parse_uint(tv, rr + ts[4], te[4] + 1u - ts[4], ok);
+    CigarWalk cw;
+    cw.begin(r);
+    const uint32_t clen = te[5] + 1u - ts[5];
+    for (uint32_t i = 0; i < clen; i += 4u) {
+        uint32_t w = win_load4(tv, rr + ts[5] + i);
+        const uint32_t m = clen - i < 4u ? clen - i : 4u;
+        for (uint32_t b = 0; b < m; ++b) { cw.step(r, (uint8_t)(w & 0xFFu), i + b + 1u == clen); w >>= 8; }
+    }
+    cw.end(r);
+    r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;
+    return PF_OK;
+}
+
+MKT_HD uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
+
 // bytewise std::string::compare of two byte ranges of the block
 MKT_HD int text_cmp(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
-    uint32_t m = alen < blen ? alen : blen;
-    for (uint32_t i = 0; i < m; ++i) {
-        int d = (int)tv.at(a + i) - (int)tv.at(b + i);
-        if (d) return d;
+    const uint32_t m = alen < blen ? alen : blen;
+    if (tv.inside(a, alen) && tv.inside(b, blen)) {
+        const uint32_t ra = a - tv.w0, rb = b - tv.w0;
+        for (uint32_t i = 0; i < m; i += 4u) {
+            uint32_t x = win_load4(tv, ra + i), y = win_load4(tv, rb + i);
+            if (m - i < 4u) { const uint32_t k = (1u << ((m - i) * 8u)) - 1u; x &= k; y &= k; }
+            if (x != y) return bswap32(x) < bswap32(y) ? -1 : 1;      // first differing byte decides
+        }
+    } else {
+        for (uint32_t i = 0; i < m; ++i) {
+            int d = (int)tv.at(a + i) - (int)tv.at(b + i);
+            if (d) return d;
+        }
     }
     return alen < blen ? -1 : (alen > blen ? 1 : 0);
 }
 MKT_HD bool text_eq(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
     if (alen != blen) return false;
+    if (tv.inside(a, alen) && tv.inside(b, blen)) {
+        const uint32_t ra = a - tv.w0, rb = b - tv.w0;
+        for (uint32_t i = 0; i < alen; i += 4u) {
+            uint32_t x = win_load4(tv, ra + i) ^ win_load4(tv, rb + i);
+            if (alen - i < 4u) x &= (1u << ((alen - i) * 8u)) - 1u;
+            if (x) return false;
+        }
+        return true;
+    }
     for (uint32_t i = 0; i < alen; ++i)
         if (tv.at(a + i) != tv.at(b + i)) return false;
     return true;
@@ -340,20 +480,49 @@ MKT_HD uint32_t dec_digits(uint32_t v) {
 MKT_HD uint32_t pair_line_len(uint32_t qn_len, const Verdict& v) {
     return qn_len + v.chrA_len + v.chrB_len + dec_digits(v.posA) + dec_digits(v.posB) + 9u;   // 6 tabs, 2 strands, newline
 }
-template <class Sink> MKT_HD void put_dec(Sink& s, uint32_t v) {
-    uint32_t d = dec_digits(v);
-    uint32_t div = 1;
-    for (uint32_t i = 1; i < d; ++i) div *= 10u;
-    for (uint32_t i = 0; i < d; ++i) { s.put((uint8_t)('0' + (v / div) % 10u)); div /= 10u; }
+MKT_HD uint32_t dec_digit(uint32_t v, uint32_t from_right) {      // digit 10^from_right of v
+    switch (from_right) {
+    case 0: return v % 10u;
+    case 1: return (v / 10u) % 10u;
+    case 2: return (v / 100u) % 10u;
+    case 3: return (v / 1000u) % 10u;
+    case 4: return (v / 10000u) % 10u;
+    case 5: return (v / 100000u) % 10u;
+    case 6: return (v / 1000000u) % 10u;
+    case 7: return (v / 10000000u) % 10u;
+    case 8: return (v / 100000000u) % 10u;
+    default: return (v / 1000000000u) % 10u;
+    }
 }
-template <class Sink> MKT_HD void put_text(Sink& s, const TextView& tv, uint32_t off, uint32_t len) {
-    for (uint32_t i = 0; i < len; ++i) s.put(tv.at(off + i));
-}
-template <class Sink> MKT_HD void format_pair(Sink& s, const TextView& tv, uint32_t qn_abs, uint32_t qn_len, const Verdict& v) {
-    put_text(s, tv, qn_abs, qn_len); s.put('\t');
-    put_text(s, tv, v.chrA_off, v.chrA_len); s.put('\t'); put_dec(s, v.posA); s.put('\t');
-    put_text(s, tv, v.chrB_off, v.chrB_len); s.put('\t'); put_dec(s, v.posB); s.put('\t');
-    s.put(v.sA); s.put('\t'); s.put(v.sB); s.put('\n');
+// byte k of  rid \t chrA \t posA \t chrB \t posB \t sA \t sB \n   (flash2pairs.h:123-127)
+MKT_HD uint8_t pair_line_byte(const TextView& tv, uint32_t qn_abs, uint32_t qn_len, const Verdict& v, uint32_t k) {
+    if (k < qn_len) return tv.at(qn_abs + k);
+    k -= qn_len;
+    if (k == 0) return '\t';
+    k -= 1;
+    if (k < v.chrA_len) return tv.at(v.chrA_off + k);
+    k -= v.chrA_len;
+    if (k == 0) return '\t';
+    k -= 1;
+    const uint32_t dA = dec_digits(v.posA);
+    if (k < dA) return (uint8_t)('0' + dec_digit(v.posA, dA - 1u - k));
+    k -= dA;
+    if (k == 0) return '\t';
+    k -= 1;
+    if (k < v.chrB_len) return tv.at(v.chrB_off + k);
+    k -= v.chrB_len;
+    if (k == 0) return '\t';
+    k -= 1;
+    const uint32_t dB = dec_digits(v.posB);
+    if (k < dB) return (uint8_t)('0' + dec_digit(v.posB, dB - 1u - k));
+    k -= dB;
+    switch (k) {
+    case 0: return '\t';
+    case 1: return v.sA;
+    case 2: return '\t';
+    case 3: return v.sB;
+    default: return '\n';
+    }
 }
 
 // Quirk Q2: does surviving group g of K contribute to the LOGGED selfCircle?

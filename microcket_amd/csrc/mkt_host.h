@@ -37,7 +37,7 @@ struct RunAccum {
     uint64_t groups = 0, emitted = 0, pair_bytes = 0, sam_bytes = 0;
     uint64_t counters[C_COUNT] = {0};
     uint64_t sc = 0;                   // self-circle groups so far (their indices live in the sc list)
-    TileLast pending = {0, 0, 0, 0};   // newest group (its bytes are the tail of the output so far)
+    TileLast pending = {0, 0, 0, 0, 0, 0};   // newest group (held back: it may be the input's last, quirk Q1)
 
     void add_block(const BlockResult& r) {
         sc += r.sc;
@@ -47,7 +47,7 @@ struct RunAccum {
     }
     // drop_last: this shard holds the input's last group (Q1).  group_offset / K_total place the
     // shard in the whole input (single process: 0 and `groups`).
-    // sc_idx: shard-local indices of the self-circle groups, in input order (`sc` entries).
+    // sc_idx: shard-local indices of the self-circle groups (`sc` entries, any order).
     RunStats finish(bool drop_last, uint32_t ref_threads, uint64_t group_offset, uint64_t K_total, const uint64_t* sc_idx) const {
         RunStats s;
         memset(&s, 0, sizeof s);
@@ -57,12 +57,14 @@ struct RunAccum {
         s.pairs = emitted; s.pair_bytes = pair_bytes; s.sam_bytes = sam_bytes;
         if (drop_last && pending.valid) {
             if (pending.counter) --c[pending.counter];
-            if (pending.counter == C_SELFCIRCLE && n_sc) --n_sc;      // it is the newest entry
             if (pending.pair_bytes) { --s.pairs; s.pair_bytes -= pending.pair_bytes; s.sam_bytes -= pending.sam_bytes; }
         }
         uint64_t logged = 0;
-        for (uint64_t k = 0; k < n_sc; ++k)
+        const bool drop = drop_last && pending.valid;
+        for (uint64_t k = 0; k < n_sc; ++k) {
+            if (drop && sc_idx[k] + 1 == groups) continue;             // the dropped last group
             if (selfcircle_logged(group_offset + sc_idx[k], K_total, ref_threads)) ++logged;
+        }
         for (int k = 0; k < (int)C_COUNT; ++k) s.counters[k] = (uint32_t)c[k];     // u32 wrap as the reference's kstat
         s.selfcircle_all = (uint32_t)c[C_SELFCIRCLE];
         s.counters[C_SELFCIRCLE] = (uint32_t)logged;

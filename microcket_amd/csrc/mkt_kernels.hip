@@ -21,6 +21,21 @@ constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
 
 struct ScanScratch { uint64_t a[NT / 64], b[NT / 64]; };
 
+// Diagnostic build only (-DMKT_STAMPS): per-phase shader-clock shares, accumulated by lane 0 of
+// every tile into a.stamps[phase].  Never compiled into the shipped library.
+#if defined(MKT_STAMPS)
+#define STAMP(k)                                                                        \
+    do {                                                                                \
+        if (tid == 0 && a.stamps) {                                                     \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
+            if ((k) > 0) atomicAdd(&a.stamps[(k)], now_ - stamp_prev_);                 \
+            stamp_prev_ = now_;                                                         \
+        }                                                                               \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 __device__ inline uint64_t shfl_up64(uint64_t v, int d) { return (uint64_t)__shfl_up((long long)v, d, 64); }
 __device__ inline uint64_t shfl_xor64(uint64_t v, int d) { return (uint64_t)__shfl_xor((long long)v, d, 64); }
 
@@ -47,11 +62,16 @@ __device__ inline void block_exscan2(uint64_t& a, uint64_t& b, uint64_t& ta, uin
     __syncthreads();
 }
 
-// exact per-byte "== '\n'" mask of a dword, one bit per byte
-__device__ inline uint32_t nl_bits(uint32_t x) {
-    uint32_t y = x ^ 0x0A0A0A0Au;
-    uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);    // 0x80 where the byte is zero
-    return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u);
+// 0x80 in every byte of x that is zero (exact, no cross-byte borrow)
+__device__ inline uint32_t zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }
+// 0x80 in every byte of x that is >= n (1 <= n <= 128), bytes >= 0x80 included
+__device__ inline uint32_t ge_bytes(uint32_t x, uint32_t n) { return (((x & 0x7F7F7F7Fu) + (0x80u - n) * 0x01010101u) | x) & 0x80808080u; }
+__device__ inline uint32_t pack_msb(uint32_t z) { return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u); }
+// per-byte masks of a dword: newline, whitespace (space, \t \n \v \f \r), one bit per byte
+__device__ inline uint32_t nl_bits(uint32_t x) { return pack_msb(zero_bytes(x ^ 0x0A0A0A0Au)); }
+__device__ inline uint32_t ws_bits(uint32_t x) {
+    const uint32_t ctl = ge_bytes(x, 9u) & ~ge_bytes(x, 14u);        // 9..13
+    return pack_msb(ctl | zero_bytes(x ^ 0x20202020u));
 }
 
 // Decoupled look-back on one descriptor word per tile.  Executed by one full wave.
@@ -93,58 +113,76 @@ __device__ inline uint64_t lookback(uint64_t* desc, uint32_t t, uint64_t agg, ui
 template <class Cfg>
 __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
     __shared__ TileState<Cfg> st;
-    __shared__ uint16_t nlmask[Cfg::W / 16];
     __shared__ ScanScratch scan;
     __shared__ uint32_t s_tile;
-    constexpr int NVEC = Cfg::W / 16;
+    constexpr int NVEC = (Cfg::W + 15) / 16;
+    constexpr int NM16 = Cfg::MW * 4;                  // 16-bit mask slots (incl. zero padding)
     constexpr int VPT = (NVEC + NT - 1) / NT;          // newline-mask words per thread
     constexpr int IPT = (Cfg::LCAP + NT - 1) / NT;     // line-table items per thread in the sums
     const int tid = threadIdx.x;
     const Params P = a.P;
     const uint32_t n = a.n;
     OutPtrs out = a.out;
-    out.group_base = a.run->groups;       // written by the previous block's k_finish (stream order)
-    out.sc_base = a.run->sc;
+    out.sc_base = a.run->sc;              // written by the previous block's k_finish (stream order)
+    uint16_t* nlmask = reinterpret_cast<uint16_t*>(st.u.m.nlm);
+    uint16_t* wsmask = reinterpret_cast<uint16_t*>(st.u.m.wsm);
+#if defined(MKT_STAMPS)
+    unsigned long long stamp_prev_ = 0;
+#endif
 
     for (;;) {
         if (tid == 0) { s_tile = atomicAdd(a.ticket, 1u); tile_reset(st); }
         __syncthreads();
         const uint32_t t = s_tile;
         if (t >= a.ntiles) break;
+        STAMP(0);
         const TileGeom G = tile_geom<Cfg>(t, n);
         const uint32_t wlen = G.w1 - G.w0;
         const uint32_t nvec = (wlen + 15u) >> 4;
-        TextView tv;
-        tv.g = a.text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = wlen;
+        const TextView tv = tile_view(st, a.text, n, G);
 
-        // ---- stage window in LDS, build the newline mask -------------------------------------
-        for (uint32_t v = tid; v < nvec; v += NT) {
-            const uint32_t go = G.w0 + (v << 4);
-            uint4 x;
-            if (go + 16u <= n) {
-                x = *reinterpret_cast<const uint4*>(a.text + go);
-            } else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t b = 0; go + b < n; ++b) w[b >> 2] |= (uint32_t)a.text[go + b] << ((b & 3u) * 8u);
-                x = make_uint4(w[0], w[1], w[2], w[3]);
+        // ---- stage window in LDS, build the newline / whitespace bitmaps ------------------------
+        for (uint32_t v = tid; v < (uint32_t)NM16; v += NT) {
+            uint32_t mnl = 0, mws = 0;
+            if (v < nvec) {
+                const uint32_t go = G.w0 + (v << 4);
+                uint4 x;
+                if (go + 16u <= n) {
+                    x = *reinterpret_cast<const uint4*>(a.text + go);
+                } else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t b = 0; go + b < n; ++b) w[b >> 2] |= (uint32_t)a.text[go + b] << ((b & 3u) * 8u);
+                    x = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *reinterpret_cast<uint4*>(&st.win[v << 4]) = x;
+                mnl = nl_bits(x.x) | (nl_bits(x.y) << 4) | (nl_bits(x.z) << 8) | (nl_bits(x.w) << 12);
+                mws = ws_bits(x.x) | (ws_bits(x.y) << 4) | (ws_bits(x.z) << 8) | (ws_bits(x.w) << 12);
+                const uint32_t r0 = v << 4;
+                if (r0 + 16u > wlen) {                    // bytes past the window end read as "nothing"
+                    const uint32_t keep = wlen - r0;
+                    mnl &= (1u << keep) - 1u; mws &= (1u << keep) - 1u;
+                }
+            } else if (v == nvec && (v << 4) < (uint32_t)(Cfg::W + 16)) {
+                *reinterpret_cast<uint4*>(&st.win[v << 4]) = make_uint4(0, 0, 0, 0);     // zero pad for win_load4
             }
-            *reinterpret_cast<uint4*>(&st.win[v << 4]) = x;
-            uint32_t m = nl_bits(x.x) | (nl_bits(x.y) << 4) | (nl_bits(x.z) << 8) | (nl_bits(x.w) << 12);
-            // a '\n' at window position r opens a line at r+1: keep r <= wlen-2 only
-            const uint32_t r0 = v << 4;
-            if (r0 + 16u > wlen - 1u) {
-                const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u;     // valid bit count
-                m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u);
-            }
-            nlmask[v] = (uint16_t)m;
+            nlmask[v] = (uint16_t)mnl;
+            wsmask[v] = (uint16_t)mws;
         }
         __syncthreads();
+        STAMP(1);
 
         // ---- line table: exclusive scan of newline counts ------------------------------------
         {
             uint64_t cnt = 0, dummy = 0, total, td;
             const uint32_t v0 = tid * VPT;
-            for (uint32_t k = 0; k < (uint32_t)VPT; ++k) if (v0 + k < nvec) cnt += __popc((uint32_t)nlmask[v0 + k]);
+            // a '\n' at window byte r opens a line at r+1: only r <= wlen-2 counts
+            auto line_bits = [&](uint32_t v) -> uint32_t {
+                uint32_t m = nlmask[v];
+                const uint32_t r0 = v << 4;
+                if (r0 + 16u > wlen - 1u) { const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u; m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u); }
+                return m;
+            };
+            for (uint32_t k = 0; k < (uint32_t)VPT; ++k) if (v0 + k < nvec) cnt += __popc(line_bits(v0 + k));
             uint64_t ex = cnt;
             block_exscan2(ex, dummy, total, td, scan);
             const uint32_t lead = G.w0 == 0 ? 1u : 0u;
@@ -155,7 +193,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
                 uint32_t idx = (uint32_t)ex + lead;
                 for (uint32_t k = 0; k < (uint32_t)VPT; ++k) {
                     if (v0 + k >= nvec) break;
-                    uint32_t m = nlmask[v0 + k];
+                    uint32_t m = line_bits(v0 + k);
                     while (m) {
                         const uint32_t b = __builtin_ctz(m);
                         st.off[idx++] = G.w0 + ((v0 + k) << 4) + b + 1u;
@@ -168,39 +206,45 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
         __syncthreads();
         const uint32_t NL = st.NL;
 
+        STAMP(2);
         for (uint32_t i = tid; i < NL; i += NT) ph_parse(st, tv, P, G, i);
         __syncthreads();
-        const uint32_t first_idx = st.first_idx, end_idx = st.end_idx;
-        for (uint32_t i = first_idx + tid; i < NL; i += NT) ph_start(st, tv, P, i);
+        if (tid == 0) tile_trim(st);
         __syncthreads();
+        STAMP(3);
+        const uint32_t first_idx = st.first_idx, end_idx = st.end_idx;
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) ph_group(st, tv, P, G, i);
         __syncthreads();
+        STAMP(4);
+        STAMP(5);
 
         // ---- exclusive sums over the tile's groups ---------------------------------------------
         {
+            auto& g = st.u.g;
             uint64_t ca = 0, cb = 0;                       // ca: groups | emitted<<16 | sc<<32 ; cb: pair | sam<<32
             const uint32_t i0 = first_idx + tid * IPT;
             for (uint32_t k = 0; k < (uint32_t)IPT; ++k) {
                 const uint32_t i = i0 + k;
                 if (i >= end_idx) break;
-                const uint32_t info = st.g_info[i];
+                const uint32_t info = g.g_info[i];
                 if (info & GI_START) ca += 1ull;
                 if (info & GI_EMIT) ca += 1ull << 16;
                 if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ca += 1ull << 32;
-                cb += (uint64_t)st.g_plen[i] | ((uint64_t)st.g_slen[i] << 32);
+                cb += (uint64_t)g.g_plen[i] | ((uint64_t)g.g_slen[i] << 32);
             }
             uint64_t ea = ca, eb = cb, ta, tb;
             block_exscan2(ea, eb, ta, tb, scan);
             for (uint32_t k = 0; k < (uint32_t)IPT; ++k) {
                 const uint32_t i = i0 + k;
                 if (i >= end_idx) break;
-                st.x_grp[i] = (uint16_t)(ea & 0xFFFFu); st.x_emit[i] = (uint16_t)((ea >> 16) & 0xFFFFu); st.x_sc[i] = (uint16_t)((ea >> 32) & 0xFFFFu);
-                st.x_pair[i] = (uint32_t)eb; st.x_sam[i] = (uint32_t)(eb >> 32);
-                const uint32_t info = st.g_info[i];
+                g.x_grp[i] = (uint16_t)(ea & 0xFFFFu); g.x_sc[i] = (uint16_t)((ea >> 32) & 0xFFFFu);
+                g.x_pair[i] = (uint32_t)eb; g.x_sam[i] = (uint32_t)(eb >> 32);
+                const uint32_t info = g.g_info[i];
+                if (info & GI_EMIT) g.em_idx[(ea >> 16) & 0xFFFFu] = (uint16_t)i;
                 if (info & GI_START) ea += 1ull;
                 if (info & GI_EMIT) ea += 1ull << 16;
                 if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ea += 1ull << 32;
-                eb += (uint64_t)st.g_plen[i] | ((uint64_t)st.g_slen[i] << 32);
+                eb += (uint64_t)g.g_plen[i] | ((uint64_t)g.g_slen[i] << 32);
             }
             if (tid == 0) {
                 st.sums.groups = (uint32_t)(ta & 0xFFFFu); st.sums.emitted = (uint32_t)((ta >> 16) & 0xFFFFu); st.sums.sc = (uint32_t)((ta >> 32) & 0xFFFFu);
@@ -208,9 +252,10 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             }
         }
         __syncthreads();
-
-        // ---- block-wide exclusive prefix: three descriptor words, one wave each ----------------
-        {
+        STAMP(6);
+        // ---- where do this tile's outputs go? ----------------------------------------------------
+        if (a.ordered) {
+            // input order: decoupled look-back over three descriptor words, one wave each
             const int wv = tid >> 6;
             if (wv == 0) {
                 uint64_t ex = lookback(a.descA, t, ((uint64_t)st.sums.groups << 31) | st.sums.emitted, &a.res->err);
@@ -221,66 +266,102 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             } else if (wv == 2) {
                 uint64_t ex = lookback(a.descC, t, st.sums.sam_bytes, &a.res->err);
                 if ((tid & 63) == 0) st.base.sam_bytes = ex;
+            } else if (tid == 192) {
+                atomicAdd((unsigned long long*)&a.res->pair_bytes, (unsigned long long)st.sums.pair_bytes);
+                atomicAdd((unsigned long long*)&a.res->sam_bytes, (unsigned long long)st.sums.sam_bytes);
+                atomicAdd((unsigned long long*)&a.res->sc, (unsigned long long)st.sums.sc);
+                atomicAdd((unsigned long long*)&a.res->emitted, (unsigned long long)st.sums.emitted);
             }
+        } else if (tid < 4) {
+            // any order (the reference's own order is thread-schedule dependent): one atomic range per stream
+            if (tid == 0) st.base.pair_bytes = st.sums.pair_bytes ? (uint32_t)atomicAdd((unsigned long long*)&a.res->pair_bytes, (unsigned long long)st.sums.pair_bytes) : 0u;
+            else if (tid == 1) st.base.sam_bytes = st.sums.sam_bytes ? atomicAdd((unsigned long long*)&a.res->sam_bytes, (unsigned long long)st.sums.sam_bytes) : 0ull;
+            else if (tid == 2) st.base.sc = st.sums.sc ? (uint32_t)atomicAdd((unsigned long long*)&a.res->sc, (unsigned long long)st.sums.sc) : 0u;
+            else if (st.sums.emitted) atomicAdd((unsigned long long*)&a.res->emitted, (unsigned long long)st.sums.emitted);
         }
+        if (tid == 5) a.tile_groups[t] = st.sums.groups;
         __syncthreads();
+        STAMP(7);
 
         // ---- emit ------------------------------------------------------------------------------
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
-            ph_emit(st, tv, P, out, i);
+            ph_account(st, tv, P, out, t, i);
             ph_last(st, &a.tile_last[t], i);
         }
-        __syncthreads();
-        {   // staged .pairs bytes -> global
-            const uint32_t used = st.stg_used;
+        {   // .pairs bytes: one lane per output byte, coalesced stores
+            const uint32_t total = st.sums.pair_bytes;
             const uint64_t go = st.base.pair_bytes;
-            if (go + used <= out.pairs_cap) { for (uint32_t k = tid; k < used; k += NT) out.pairs[go + k] = st.stg[k]; }
-            else if (tid == 0 && used) st.err |= E_PAIRS_CAP;
+            if (go + total <= out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) out.pairs[go + k] = tile_pair_byte(st, tv, k); }
+            else if (tid == 0 && total) st.err |= E_PAIRS_CAP;
         }
         if (P.write_sam) {   // contiguous groups: straight byte-range copies
             for (uint32_t i = first_idx; i < end_idx; ++i) {
-                const uint32_t info = st.g_info[i];
+                const uint32_t info = st.u.g.g_info[i];
                 if ((info & (GI_EMIT | GI_CONTIG)) != (GI_EMIT | GI_CONTIG)) continue;
-                const uint32_t len = st.g_slen[i], src = st.off[i];
-                const uint64_t go = st.base.sam_bytes + st.x_sam[i];
+                const uint32_t len = st.u.g.g_slen[i], src = st.off[i];
+                const uint64_t go = st.base.sam_bytes + st.u.g.x_sam[i];
                 if (go + len <= out.sam_cap) { for (uint32_t k = tid; k < len; k += NT) out.sam[go + k] = tv.at(src + k); }
                 else if (tid == 0) st.err |= E_SAM_CAP;
             }
         }
         __syncthreads();
+        STAMP(8);
         if (tid < (int)C_COUNT && st.cnt[tid]) atomicAdd(&a.res->counters[tid], st.cnt[tid]);
         if (tid == 0 && st.err) atomicOr(&a.res->err, st.err);
         __syncthreads();
     }
 }
 
-// totals + the block's last group (quirk Q1 bookkeeping happens on the host)
-__global__ void k_finish(KArgs a) {
+// After the tiles: exclusive scan of the per-tile group counts, self-circle entries resolved to
+// global group indices, the block's last group located (quirk Q1 bookkeeping happens on the host).
+constexpr int NTF = 1024;
+__global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
+    __shared__ uint32_t s_wave[NTF / 64];
+    __shared__ uint32_t s_carry;
     __shared__ int s_last;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_last = -1;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) { s_carry = 0; s_last = -1; }
     __syncthreads();
     int best = -1;
-    for (uint32_t t = tid; t < a.ntiles; t += blockDim.x) if (a.tile_last[t].valid) best = (int)t;
+    for (uint32_t base = 0; base < a.ntiles; base += NTF) {
+        const uint32_t t = base + tid;
+        const uint32_t x = t < a.ntiles ? a.tile_groups[t] : 0u;
+        if (t < a.ntiles && a.tile_last[t].valid) best = (int)t;
+        uint32_t inc = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+        if (lane == 63) s_wave[wv] = inc;
+        __syncthreads();
+        uint32_t pre = s_carry, tot = 0;
+        for (int w = 0; w < NTF / 64; ++w) { if (w < wv) pre += s_wave[w]; tot += s_wave[w]; }
+        if (t < a.ntiles) a.tile_groups[t] = pre + inc - x;
+        __syncthreads();
+        if (tid == 0) s_carry += tot;
+        __syncthreads();
+    }
     if (best >= 0) atomicMax(&s_last, best);
     __syncthreads();
-    if (tid == 0) {
-        BlockResult* r = a.res;
-        if (a.ntiles) {
-            const uint64_t A = a.descA[a.ntiles - 1] & PAYLOAD, B = a.descB[a.ntiles - 1] & PAYLOAD, C = a.descC[a.ntiles - 1] & PAYLOAD;
-            r->groups = A >> 31; r->emitted = A & 0x7FFFFFFFu;
-            r->pair_bytes = B >> 31; r->sc = B & 0x7FFFFFFFu;
-            r->sam_bytes = C;
+    BlockResult* r = a.res;
+    const uint64_t n_sc = r->sc, sc_base = a.run->sc, g_base = a.run->groups;
+    if (r->err == 0) {
+        for (uint64_t k = tid; k < n_sc; k += NTF) {
+            if (sc_base + k >= a.out.sc_cap) break;
+            const uint64_t e = a.out.sc[sc_base + k];
+            a.out.sc[sc_base + k] = g_base + a.tile_groups[(uint32_t)(e >> 32)] + (uint32_t)(e & 0xFFFFFFFFu);
         }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        r->groups = s_carry;
         if (s_last >= 0) r->last = a.tile_last[s_last];
         r->tiles = a.ntiles;
-        if (r->err == 0) { a.run->groups += r->groups; a.run->sc += r->sc; }     // a failed block is re-run
+        if (r->err == 0) { a.run->groups += r->groups; a.run->sc += n_sc; }     // a failed block is re-run
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-typedef TileCfg<16384, 1024, 4096, 256, 4, 4096> CfgFast;
-typedef TileCfg<256, 64, 192, 512, 4, 512> CfgSmall;
+typedef TileCfg<16384, 2048, 4096, 256, 4> CfgFast;
+typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
 
 uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : CfgFast::TILE; }
 
@@ -291,7 +372,7 @@ hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(NTF), 0, s, a);
     return hipGetLastError();
 }
 

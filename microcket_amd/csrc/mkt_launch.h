@@ -21,10 +21,13 @@ struct KArgs {
     uint64_t* descB;            //                            pair_bytes | self-circles
     uint64_t* descC;            //                            sam_bytes
     uint32_t* ticket;
+    uint32_t* tile_groups;      // per tile: groups opened in it; k_finish turns it into the exclusive prefix
+    int32_t ordered;            // 1: outputs in input order (decoupled look-back); 0: one atomic range per tile
     TileLast* tile_last;
     BlockResult* res;
     DevRun* run;
-    OutPtrs out;                // sc_base / group_base are filled by the kernel from *run
+    OutPtrs out;                // sc_base is filled by the kernel from *run
+    unsigned long long* stamps; // diagnostic builds only (MKT_STAMPS), else null
 };
 
 uint32_t tile_bytes(int cfg);

@@ -305,7 +305,10 @@ template <class S> MKT_HD void syn_group_unc(S& s, const SynParams& p, uint64_t 
     uint32_t f2 = 1u | 128u | (revB ? 16u : 0u) | (revA ? 32u : 0u);
 
     if (kind < 2) {                            // singleton: only one mate reported
-        SynAln a = syn_aln(A.chrom, A.pos, r.below(2) ? (f1 | 8u) : (f2 | 8u), syn_mapq(r));
+        // (one RNG draw per full expression everywhere: argument evaluation order differs between compilers)
+        const uint32_t which = r.below(2);
+        const uint32_t mq = syn_mapq(r);
+        SynAln a = syn_aln(A.chrom, A.pos, which ? (f1 | 8u) : (f2 | 8u), mq);
         syn_cigar_full(a, r, L);
         syn_line(s, p, gidx, a, r);
         return;
@@ -454,7 +457,7 @@ template <class S> MKT_HD void syn_group_directed(S& s, const SynParams& p, uint
         uint32_t d = dsel == 0 ? r.below(13) : dsel == 1 ? 998 + r.below(5) : dsel == 2 ? 9998 + r.below(5) : r.below(40);
         uint32_t rv1 = r.below(2), rv2 = r.below(2);
         // 5' end: left for '+', right (= pos + L - 1) for '-'
-        uint32_t five1 = P + 2000, five2 = r.below(2) ? five1 + d : five1 - d;
+        uint32_t five1 = P + 20000, five2 = r.below(2) ? five1 + d : five1 - d;     // stays positive: POS >= 2^31 is out of contract
         SynAln x = syn_lit(c, rv1 ? five1 - (L - 1) : five1, R1 | (rv1 ? 16u : 0u), 60);
         SynAln y = syn_lit(cx, rv2 ? five2 - (L - 1) : five2, R2 | (rv2 ? 16u : 0u), 60);
         syn_cig(x, L, 'M'); syn_cig(y, L, 'M');
@@ -562,7 +565,10 @@ template <class S> MKT_HD void syn_group_stress(S& s, const SynParams& p, uint64
         if (a.pos == 0) a.pos = 1;
         uint32_t fsel = r.below(100);
         uint32_t rd = fsel < 45 ? 64u : fsel < 90 ? 128u : fsel < 94 ? 0u : 192u;
-        a.flag = 1u | rd | (r.below(2) ? 16u : 0u) | (r.below(2) ? 32u : 0u) | (r.below(8) == 0 ? 2048u : 0u);
+        const uint32_t b16 = r.below(2);
+        const uint32_t b32 = r.below(2);
+        const uint32_t b2048 = r.below(8);
+        a.flag = 1u | rd | (b16 ? 16u : 0u) | (b32 ? 32u : 0u) | (b2048 == 0 ? 2048u : 0u);
         uint32_t bad = r.below(100);
         if (bad < 3) a.flag |= 256u; else if (bad < 5) a.flag |= 512u; else if (bad < 7) a.flag |= 1024u;
         uint32_t mq = r.below(100);

@@ -1,38 +1,43 @@
 // mkt_tile.h -- the per-tile algorithm of the fused sam2pairs kernel.
 //
-// A block of SAM text (< 2 GiB, starting on a QNAME-group boundary) is cut into fixed-size byte
+// A block of SAM text (< 1 GiB, starting on a QNAME-group boundary) is cut into fixed-size byte
 // tiles.  One workgroup owns one tile: it stages the tile plus a back halo and a forward halo in
 // LDS, finds the line starts, parses the six leading fields of every line in the window, decides
 // which surviving lines open a QNAME group (comparison with the previous surviving line, as
 // pairutil.h:163 does), and classifies every group whose FIRST line starts inside the tile.  Bytes
 // outside the window are reachable through TextView::at() (global memory), so halo sizes only
-// affect speed, never results: lines or groups that leave the window take the slow loops below.
+// affect speed, never results: lines or groups that leave the window take the cold loops below.
 //
 // The phases are plain functions over TileState so that the same code runs
 //   * in the HIP kernel, one work item per lane with barriers between phases (mkt_kernels.hip);
 //   * serially in the host emulation the CPU tests use to check this logic (tests/host/).
+//
+// Phases:  [load window + bitmaps] -> [line table] -> ph_parse (fields, CIGAR, "same QNAME as the
+// previous line") -> ph_group (group-start test, member walk, classification) -> tile sums ->
+// output offsets (atomic ranges, or ordered look-back) -> ph_account / per-byte .pairs / .sam copy.
 #pragma once
 #include "mkt_core.h"
 
 namespace mkt {
 
-template <int TILE_, int HB_, int HF_, int LCAP_, int OVF_, int STG_>
+template <int TILE_, int HB_, int HF_, int LCAP_, int OVF_>
 struct TileCfg {
     static constexpr int TILE = TILE_;   // bytes owned by one workgroup
     static constexpr int HB = HB_;       // back halo (previous surviving line's QNAME)
     static constexpr int HF = HF_;       // forward halo (rest of the last group)
     static constexpr int W = HB_ + TILE_ + HF_;
     static constexpr int LCAP = LCAP_;   // line-table capacity (lines starting in the window)
-    static constexpr int OVF = OVF_;     // records parsed beyond the window that must be kept
+    static constexpr int OVF = OVF_;     // kept records parsed beyond the window (one group: <= 4)
     static constexpr int RCAP = LCAP_ + OVF_;
-    static constexpr int STG = STG_;     // LDS staging for the tile's .pairs bytes
+    static constexpr int MW = (W + 63) / 64 + 3;   // bitmap words incl. zero padding
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
+    static_assert(LCAP_ + OVF_ < 0xFFFF, "record indices are 16 bit");
 };
 
 enum ErrBits : uint32_t {
     E_LINE_TABLE = 1,     // more line starts in a window than LCAP: rerun with the small-tile config
-    E_OVF_SLOTS = 2,      // more kept out-of-window records than OVF: rerun with the small-tile config
-    E_LOOKBACK = 4,       // decoupled look-back spin bound hit (never expected)
+    E_OVF_SLOTS = 2,      // more kept out-of-window records than OVF (cannot happen with OVF >= 4)
+    E_LOOKBACK = 4,       // ordered mode: decoupled look-back spin bound hit (never expected)
     E_PAIRS_CAP = 8,      // .pairs output buffer too small (sizes in the result are still exact)
     E_SAM_CAP = 16,       // .sam output buffer too small
     E_SC_CAP = 32,        // self-circle index buffer too small
@@ -53,10 +58,13 @@ template <class Cfg> MKT_HD TileGeom tile_geom(uint32_t tile, uint32_t n) {
 }
 MKT_HD uint32_t num_tiles(uint32_t n, uint32_t tile_bytes) { return n == 0 ? 0u : (n + tile_bytes - 1) / tile_bytes; }
 
+// line bits
+constexpr uint8_t LB_SURVIVE = 1, LB_EQPREV = 2, LB_CUT = 4;   // EQPREV: same QNAME token as the line before (table index - 1);
+                                                               // CUT: last halo line, fields cut by the window end (not parsed)
 // per-group info word
 constexpr uint32_t GI_COUNTER = 0xF, GI_EMIT = 1u << 4, GI_CONTIG = 1u << 5, GI_SA_MINUS = 1u << 6, GI_SB_MINUS = 1u << 7, GI_START = 1u << 8;
 
-// What one tile contributes to the block-wide exclusive sums.
+// What one tile contributes to the block-wide sums.
 struct TileSums {
     uint32_t groups, emitted, sc, pair_bytes;
     uint64_t sam_bytes;
@@ -64,63 +72,83 @@ struct TileSums {
 
 struct TileLast {          // the tile's last group (quirk Q1 bookkeeping on the host)
     uint32_t counter, pair_bytes, sam_bytes, valid;
+    uint32_t pair_off, sam_off;      // where its bytes sit in the block's outputs
 };
 
+// LDS-resident state of one tile.
 template <class Cfg>
 struct TileState {
-    alignas(16) uint8_t win[Cfg::W];
-    alignas(16) uint8_t stg[Cfg::STG];
+    alignas(16) uint8_t win[Cfg::W + 16];          // + zero pad for the dword loads
     // records: [0, LCAP) lines of the window, [LCAP, RCAP) kept records parsed beyond it
     uint32_t off[Cfg::RCAP];
     uint32_t pos[Cfg::RCAP];
     int32_t lclip[Cfg::RCAP], rclip[Cfg::RCAP], mappable[Cfg::RCAP];
-    int32_t left0[Cfg::RCAP], left1[Cfg::RCAP], right0[Cfg::RCAP], right1[Cfg::RCAP], rightLast[Cfg::RCAP];
+    int32_t right0[Cfg::RCAP], left1[Cfg::RCAP], right1[Cfg::RCAP];     // left0 == pos
     uint16_t qn_off[Cfg::RCAP], qn_len[Cfg::RCAP], rn_off[Cfg::RCAP], rn_len[Cfg::RCAP];
     uint16_t flag[Cfg::RCAP];
     uint8_t segCnt[Cfg::RCAP];
-    uint8_t bits[Cfg::LCAP];             // 1 = survives, 2 = opens a group
-    uint32_t end[Cfg::LCAP];             // offset of the line's '\n' (or n), kUnknown if past the window
-    // group results, indexed by the group's first line
-    uint32_t g_info[Cfg::LCAP], g_posA[Cfg::LCAP], g_posB[Cfg::LCAP];
-    uint32_t g_chrA[Cfg::LCAP], g_chrB[Cfg::LCAP];
-    uint16_t g_chrA_len[Cfg::LCAP], g_chrB_len[Cfg::LCAP];
-    uint32_t g_plen[Cfg::LCAP], g_slen[Cfg::LCAP], g_last_end[Cfg::LCAP];
-    // exclusive sums inside the tile
-    uint32_t x_pair[Cfg::LCAP], x_sam[Cfg::LCAP];
-    uint16_t x_grp[Cfg::LCAP], x_emit[Cfg::LCAP], x_sc[Cfg::LCAP];
+    uint8_t bits[Cfg::LCAP];             // LB_*
+    union alignas(16) Phase {
+        struct {                         // while parsing: bitmaps over the window (bit r <-> byte r)
+            uint64_t nlm[Cfg::MW];       // newline
+            uint64_t wsm[Cfg::MW];       // whitespace
+        } m;
+        struct {                         // afterwards: group results (indexed by the group's first line) + tile-local sums
+            uint32_t g_info[Cfg::LCAP], g_posA[Cfg::LCAP], g_posB[Cfg::LCAP];
+            uint32_t g_chrA[Cfg::LCAP], g_chrB[Cfg::LCAP];
+            uint16_t g_chrA_len[Cfg::LCAP], g_chrB_len[Cfg::LCAP];
+            uint32_t g_plen[Cfg::LCAP], g_slen[Cfg::LCAP], g_last_end[Cfg::LCAP];
+            uint32_t x_pair[Cfg::LCAP], x_sam[Cfg::LCAP];
+            uint16_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP];
+            uint16_t em_idx[Cfg::LCAP];  // emit ordinal -> first line of the emitting group
+        } g;
+    } u;
     // scalars
-    uint32_t NL, first_idx, end_idx, ovf_n, err, stg_used;
+    uint32_t NL, first_idx, end_idx, ovf_n, err, last_line_end;
     uint32_t cnt[C_COUNT];
     TileSums sums;            // this tile's totals
-    TileSums base;            // exclusive prefix over earlier tiles
+    TileSums base;            // where this tile's outputs start
 };
 
+#if defined(__HIPCC__)
+#define MKT_COLD __host__ __device__ inline __attribute__((noinline))
+#else
+#define MKT_COLD inline __attribute__((noinline))
+#endif
+
+template <class Cfg> MKT_HD TextView tile_view(const TileState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G) {
+    TextView tv;
+    tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = G.w1 - G.w0; tv.nlm = st.u.m.nlm; tv.wsm = st.u.m.wsm;
+    return tv;
+}
+
 template <class Cfg> MKT_HD void tile_reset(TileState<Cfg>& st) {
-    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.ovf_n = 0; st.err = 0; st.stg_used = 0;
+    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.ovf_n = 0; st.err = 0; st.last_line_end = kUnknown;
     for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
 }
 
-template <class Cfg> MKT_HD void store_rec(TileState<Cfg>& st, uint32_t idx, const Rec& r, bool* survive) {
+MKT_HD bool rec_in_range(const Rec& r) { return r.qn_off <= 0xFFFFu && r.qn_len <= 0xFFFFu && r.rn_off <= 0xFFFFu && r.rn_len <= 0xFFFFu; }
+
+template <class Cfg> MKT_HD bool store_rec(TileState<Cfg>& st, uint32_t idx, const Rec& r) {
     bool s = r.survive;
-    if (r.qn_off > 0xFFFFu || r.qn_len > 0xFFFFu || r.rn_off > 0xFFFFu || r.rn_len > 0xFFFFu) {
+    if (!rec_in_range(r)) {
         if (s) st.err |= E_FIELD_RANGE;     // benign race: every writer ORs the same bit
         s = false;
     }
     st.off[idx] = r.off; st.pos[idx] = r.pos;
     st.lclip[idx] = r.lclip; st.rclip[idx] = r.rclip; st.mappable[idx] = r.mappable;
-    st.left0[idx] = r.left0; st.left1[idx] = r.left1; st.right0[idx] = r.right0; st.right1[idx] = r.right1;
-    st.rightLast[idx] = r.rightLast;
+    st.right0[idx] = r.right0; st.left1[idx] = r.left1; st.right1[idx] = r.right1;
     st.qn_off[idx] = (uint16_t)r.qn_off; st.qn_len[idx] = (uint16_t)r.qn_len;
     st.rn_off[idx] = (uint16_t)r.rn_off; st.rn_len[idx] = (uint16_t)r.rn_len;
     st.flag[idx] = (uint16_t)(r.flag & 0xFFFFu);
     st.segCnt[idx] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
-    *survive = s;
+    return s;
 }
 template <class Cfg> MKT_HD Seg load_seg(const TileState<Cfg>& st, uint32_t idx) {
     Seg s;
     s.segCnt = st.segCnt[idx]; s.lclip = st.lclip[idx]; s.rclip = st.rclip[idx]; s.mappable = st.mappable[idx];
-    s.left0 = st.left0[idx]; s.left1 = st.left1[idx]; s.right0 = st.right0[idx]; s.right1 = st.right1[idx];
-    s.rightLast = st.rightLast[idx];
+    s.left0 = (int32_t)st.pos[idx]; s.left1 = st.left1[idx]; s.right0 = st.right0[idx]; s.right1 = st.right1[idx];
+    s.rightLast = s.segCnt == 2 ? s.right1 : s.right0;       // right[segCnt-1]; only read when segCnt is 1 or 2
     s.flag = st.flag[idx]; s.pos = st.pos[idx];
     s.chr_off = st.off[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];
     return s;
@@ -137,28 +165,74 @@ MKT_HD uint32_t find_newline(const TextView& tv, uint32_t from) {     // offset 
     while (p < tv.n && tv.at(p) != '\n') ++p;
     return p;
 }
+// offset of line i's '\n' (or n); kUnknown when it lies past the window
+template <class Cfg> MKT_HD uint32_t line_end(const TileState<Cfg>& st, uint32_t i) {
+    return i + 1 < st.NL ? st.off[i + 1] - 1u : st.last_line_end;
+}
 
 // ---- phase: parse line i of the window -------------------------------------------------------
+// first whitespace-delimited token of the line starting at `off` (generic; used for odd lines)
+MKT_COLD void first_token(const TextView& tv, uint32_t off, uint32_t* ts, uint32_t* len) {
+    uint32_t p = off;
+    while (p < tv.n) { uint8_t c = tv.at(p); if (c == '\n' || !is_ws(c)) break; ++p; }
+    *ts = p;
+    while (p < tv.n) { uint8_t c = tv.at(p); if (c == '\n' || is_ws(c)) break; ++p; }
+    *len = p - *ts;
+}
+
 template <class Cfg> MKT_HD void ph_parse(TileState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
     const uint32_t off = st.off[i];
-    uint32_t e;
-    if (i + 1 < st.NL) e = st.off[i + 1] - 1;
-    else {
-        e = kUnknown;
-        for (uint32_t p = off; p < G.w1; ++p) if (tv.at(p) == '\n') { e = p; break; }
-        if (e == kUnknown && G.w1 >= tv.n) e = tv.n;
+    if (i + 1 == st.NL) {
+        // last line of the table: a '\n' before the window's last byte would have opened another line
+        uint32_t e;
+        if (G.w1 - 1 >= off && tv.win[G.w1 - 1 - G.w0] == '\n') e = G.w1 - 1;
+        else e = G.w1 >= tv.n ? tv.n : kUnknown;
+        st.last_line_end = e;
     }
-    st.end[i] = e;
-    Rec r = parse_record(tv, off, P);
-    bool s;
-    store_rec(st, i, r, &s);
-    st.bits[i] = s ? 1 : 0;
+    Rec r;
+    const int pf = parse_record_fast(tv, off, P, r);
+    if (pf == PF_CUT && off >= G.t1) {
+        // a halo line whose fields run past the window end: it is only ever needed by a group that
+        // spans the whole forward halo; leave it to the out-of-window walk (group_walk_beyond)
+        st.bits[i] = LB_CUT;
+        return;
+    }
+    if (pf != PF_OK) r = parse_record(tv, off, P);
+    uint8_t b = store_rec(st, i, r) ? LB_SURVIVE : 0;
+    // same QNAME token as the line before?  (table lines are adjacent lines of the text)
+    if (i > 0 && r.qn_len > 0) {
+        const uint32_t poff = st.off[i - 1];
+        const uint32_t qa = off + r.qn_off, ql = r.qn_len;
+        bool eq;
+        if (!is_ws(tv.at(poff)) && tv.inside(poff, ql + 1u)) {
+            // the previous line's first token starts at its first byte: equal iff the bytes match
+            // and the token ends right after them
+            eq = text_eq(tv, qa, ql, poff, ql) && is_ws(tv.at(poff + ql));
+        } else {
+            uint32_t pts, plen;
+            first_token(tv, poff, &pts, &plen);
+            eq = text_eq(tv, qa, ql, pts, plen);
+        }
+        if (eq) b |= LB_EQPREV;
+    }
+    st.bits[i] = b;
     if (off >= G.t0 && (i == 0 || st.off[i - 1] < G.t0)) st.first_idx = i;
     if (off >= G.t1 && (i == 0 || st.off[i - 1] < G.t1)) st.end_idx = i;
 }
 
-// ---- phase: does surviving line i open a group? ------------------------------------------------
-template <class Cfg> MKT_HD bool resolve_back(const TileState<Cfg>& st, const TextView& tv, const Params& P, uint32_t i) {
+// After ph_parse (one thread): a trailing LB_CUT line leaves the table; the line before it becomes
+// the last one and its '\n' is the byte in front of the dropped line.
+template <class Cfg> MKT_HD void tile_trim(TileState<Cfg>& st) {
+    if (st.NL && (st.bits[st.NL - 1] & LB_CUT)) {
+        st.last_line_end = st.off[st.NL - 1] - 1u;
+        st.NL -= 1;
+        if (st.end_idx > st.NL) st.end_idx = st.NL;
+        if (st.first_idx > st.NL) st.first_idx = st.NL;
+    }
+}
+
+// ---- does surviving line i open a group?  (pairutil.h:163: QNAME != the previous SURVIVING line's)
+template <class Cfg> MKT_COLD bool start_vs_global(const TileState<Cfg>& st, const TextView& tv, const Params& P, uint32_t i) {
     // no surviving line precedes line i inside the window: walk back through global memory
     uint32_t q = st.off[0];
     const uint32_t qa = st.off[i] + st.qn_off[i], ql = st.qn_len[i];
@@ -166,20 +240,24 @@ template <class Cfg> MKT_HD bool resolve_back(const TileState<Cfg>& st, const Te
         uint32_t ls = q - 1;                          // the '\n' ending the previous line
         while (ls > 0 && tv.at(ls - 1) != '\n') --ls;
         Rec r = parse_record(tv, ls, P);
-        if (r.survive && r.qn_off <= 0xFFFFu && r.qn_len <= 0xFFFFu && r.rn_off <= 0xFFFFu && r.rn_len <= 0xFFFFu)
-            return !text_eq(tv, qa, ql, ls + r.qn_off, r.qn_len);
+        if (r.survive && rec_in_range(r)) return !text_eq(tv, qa, ql, ls + r.qn_off, r.qn_len);
         q = ls;
     }
     return true;                                      // first surviving line of the block
 }
-template <class Cfg> MKT_HD void ph_start(TileState<Cfg>& st, const TextView& tv, const Params& P, uint32_t i) {
-    if (!(st.bits[i] & 1)) return;
-    int32_t j = (int32_t)i - 1;
-    while (j >= 0 && !(st.bits[j] & 1)) --j;
-    bool start;
-    if (j >= 0) start = !text_eq(tv, st.off[i] + st.qn_off[i], st.qn_len[i], st.off[j] + st.qn_off[j], st.qn_len[j]);
-    else start = resolve_back(st, tv, P, i);
-    if (start) st.bits[i] |= 2;
+template <class Cfg> MKT_HD bool is_start(const TileState<Cfg>& st, const TextView& tv, const Params& P, uint32_t i) {
+    // precondition: line i survives
+    bool chain = true;                                // every line in (j, i] has the QNAME of its predecessor
+    uint32_t j = i;
+    for (;;) {
+        if (j == 0) return start_vs_global(st, tv, P, i);
+        chain = chain && (st.bits[j] & LB_EQPREV);
+        --j;
+        if (st.bits[j] & LB_SURVIVE) break;
+    }
+    if (chain) return false;                          // equal by transitivity
+    // some line in between has another name: compare with the previous surviving line itself
+    return !text_eq(tv, st.off[i] + st.qn_off[i], st.qn_len[i], st.off[j] + st.qn_off[j], st.qn_len[j]);
 }
 
 // ---- phase: walk the group opened by line i, classify it ---------------------------------------
@@ -187,174 +265,182 @@ template <class Cfg> MKT_HD void ph_start(TileState<Cfg>& st, const TextView& tv
 MKT_HD uint32_t lds_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 MKT_HD void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 MKT_HD void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-MKT_HD void lds_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
 #else
 MKT_HD uint32_t lds_inc(uint32_t* p) { return (*p)++; }
 MKT_HD void lds_add(uint32_t* p, uint32_t v) { *p += v; }
 MKT_HD void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
-MKT_HD void lds_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
 #endif
 
-template <class Cfg> MKT_HD void ph_group(TileState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
-    st.g_info[i] = 0; st.g_plen[i] = 0; st.g_slen[i] = 0; st.g_last_end[i] = 0;
-    st.g_posA[i] = st.g_posB[i] = 0; st.g_chrA[i] = st.g_chrB[i] = 0; st.g_chrA_len[i] = st.g_chrB_len[i] = 0;
-    if (!(st.bits[i] & 2)) return;
-    const uint32_t qa = st.off[i] + st.qn_off[i], ql = st.qn_len[i];
-    uint32_t nmem = 0, n1 = 0, n2 = 0;
-    uint32_t sa = 0xFFFFu, sb = 0xFFFFu, sc = 0xFFFFu, sd = 0xFFFFu;    // unc: r1a r1b r2a r2b; flash: a b
-    bool gap = false, contig = true;
-    uint32_t last_end = 0;          // one past the '\n' of the last member
-    uint64_t sam_bytes = 0;
-
-    // returns true when record `idx` (flag f) must be kept for the classifier
-    auto wants = [&](uint32_t f) -> int {
-        if (P.mode == MODE_FLASH) return nmem < 2 ? (int)nmem : -1;
+struct GroupWalk {
+    uint32_t nmem, n1, n2;
+    uint32_t sa, sb, sc, sd;        // unc: r1a r1b r2a r2b; flash: a b (record indices, 0xFFFF = none)
+    bool gap, contig;
+    uint32_t last_end;              // one past the '\n' of the last member
+    uint64_t sam_bytes;
+    MKT_HD int wants(int mode, uint32_t f) const {
+        if (mode == MODE_FLASH) return nmem < 2 ? (int)nmem : -1;
         if (f & 64u) return n1 < 2 ? (int)n1 : -1;
         if (f & 128u) return n2 < 2 ? 2 + (int)n2 : -1;
         return -1;
-    };
-    auto take = [&](uint32_t idx, uint32_t f, uint32_t loff, uint32_t lend) {
-        int slot = wants(f);
+    }
+    MKT_HD void take(int mode, uint32_t n, uint32_t idx, uint32_t f, uint32_t loff, uint32_t lend) {
+        const int slot = wants(mode, f);
         if (slot == 0) sa = idx; else if (slot == 1) sb = idx; else if (slot == 2) sc = idx; else if (slot == 3) sd = idx;
-        if (P.mode == MODE_UNC) { if (f & 64u) ++n1; else if (f & 128u) ++n2; }
+        if (mode == MODE_UNC) { if (f & 64u) ++n1; else if (f & 128u) ++n2; }
         ++nmem;
         if (gap) contig = false;
         sam_bytes += (uint64_t)(lend - loff) + 1u;
-        if (lend >= tv.n) contig = false;             // last line without '\n': the copy adds one
-        last_end = lend < tv.n ? lend + 1 : tv.n;
-    };
+        if (lend >= n) contig = false;                // last line without '\n': the copy adds one
+        last_end = lend < n ? lend + 1 : n;
+    }
+};
+
+// the group may continue past the window: walk line by line through global memory
+template <class Cfg> MKT_COLD void group_walk_beyond(TileState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G,
+                                                     uint32_t qa, uint32_t ql, GroupWalk& w) {
+    uint32_t le = st.last_line_end;
+    if (le == kUnknown) le = find_newline(tv, G.w1);
+    uint32_t q = le + 1;
+    while (q < tv.n) {
+        Rec r = parse_record(tv, q, P);
+        const uint32_t e = find_newline(tv, q);
+        if (r.survive && rec_in_range(r)) {
+            if (!text_eq(tv, qa, ql, q + r.qn_off, r.qn_len)) break;
+            uint32_t idx = 0xFFFFu;
+            if (w.wants(P.mode, r.flag) >= 0) {
+                uint32_t k = lds_inc(&st.ovf_n);
+                if (k < (uint32_t)Cfg::OVF) { idx = Cfg::LCAP + k; store_rec(st, idx, r); }
+                else lds_or(&st.err, E_OVF_SLOTS);
+            }
+            w.take(P.mode, tv.n, idx, r.flag, q, e);
+        } else w.gap = true;
+        q = e + 1;
+    }
+}
+
+template <class Cfg> MKT_HD void ph_group(TileState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
+    auto& g = st.u.g;
+    g.g_info[i] = 0; g.g_plen[i] = 0; g.g_slen[i] = 0;
+    if (!(st.bits[i] & LB_SURVIVE) || !is_start(st, tv, P, i)) return;
+    const uint32_t qa = st.off[i] + st.qn_off[i], ql = st.qn_len[i];
+    GroupWalk w;
+    w.nmem = w.n1 = w.n2 = 0; w.sa = w.sb = w.sc = w.sd = 0xFFFFu;
+    w.gap = false; w.contig = true; w.last_end = 0; w.sam_bytes = 0;
 
     uint32_t j = i;
-    for (;;) {
-        if (j < st.NL) {
-            const uint8_t b = st.bits[j];
-            if (j > i && (b & 2)) break;
-            if (b & 1) {
-                uint32_t e = st.end[j];
-                if (e == kUnknown) e = find_newline(tv, G.w1);
-                take(j, st.flag[j], st.off[j], e);
-            } else gap = true;
-            ++j;
-            continue;
-        }
-        if (G.w1 >= tv.n) break;                      // the window reaches the end of the block
-        // the group may continue past the window: walk line by line through global memory
-        uint32_t le = st.end[st.NL - 1];
-        if (le == kUnknown) le = find_newline(tv, G.w1);
-        uint32_t q = le + 1;
-        while (q < tv.n) {
-            Rec r = parse_record(tv, q, P);
-            const uint32_t e = find_newline(tv, q);
-            bool s = r.survive && r.qn_off <= 0xFFFFu && r.qn_len <= 0xFFFFu && r.rn_off <= 0xFFFFu && r.rn_len <= 0xFFFFu;
-            if (s) {
-                if (!text_eq(tv, qa, ql, q + r.qn_off, r.qn_len)) break;
-                uint32_t idx = 0xFFFFu;
-                if (wants(r.flag) >= 0) {
-                    uint32_t k = lds_inc(&st.ovf_n);
-                    if (k < (uint32_t)Cfg::OVF) { idx = Cfg::LCAP + k; bool dummy; store_rec(st, idx, r, &dummy); }
-                    else lds_or(&st.err, E_OVF_SLOTS);
-                }
-                take(idx, r.flag, q, e);
-            } else gap = true;
-            q = e + 1;
-        }
-        break;
+    bool closed = false;
+    while (j < st.NL) {
+        const uint8_t b = st.bits[j];
+        if (b & LB_SURVIVE) {
+            // a surviving line whose QNAME differs from the previous surviving line's closes the group
+            if (j > i) {
+                bool same;
+                if ((b & LB_EQPREV) && (st.bits[j - 1] & LB_SURVIVE)) same = true;     // the usual case
+                else same = !is_start(st, tv, P, j);
+                if (!same) { closed = true; break; }
+            }
+            uint32_t e = line_end(st, j);
+            if (e == kUnknown) e = find_newline(tv, G.w1);
+            w.take(P.mode, tv.n, j, st.flag[j], st.off[j], e);
+        } else w.gap = true;
+        ++j;
     }
+    if (!closed && G.w1 < tv.n) group_walk_beyond(st, tv, P, G, qa, ql, w);
 
     Verdict v;
-    if (P.mode == MODE_FLASH) {
-        Seg a = sa != 0xFFFFu ? load_seg(st, sa) : seg_zero();
-        Seg b = sb != 0xFFFFu ? load_seg(st, sb) : seg_zero();
-        v = classify_flash(tv, nmem, a, b, P.ratio);
-    } else {
-        Seg a = sa != 0xFFFFu ? load_seg(st, sa) : seg_zero();
-        Seg b = sb != 0xFFFFu ? load_seg(st, sb) : seg_zero();
-        Seg c = sc != 0xFFFFu ? load_seg(st, sc) : seg_zero();
-        Seg d = sd != 0xFFFFu ? load_seg(st, sd) : seg_zero();
-        v = classify_unc(tv, n1, n2, a, b, c, d, P.ratio);
+    {
+        Seg a = w.sa != 0xFFFFu ? load_seg(st, w.sa) : seg_zero();
+        Seg b = w.sb != 0xFFFFu ? load_seg(st, w.sb) : seg_zero();
+        if (P.mode == MODE_FLASH) v = classify_flash(tv, w.nmem, a, b, P.ratio);
+        else {
+            Seg c = w.sc != 0xFFFFu ? load_seg(st, w.sc) : seg_zero();
+            Seg d = w.sd != 0xFFFFu ? load_seg(st, w.sd) : seg_zero();
+            v = classify_unc(tv, w.n1, w.n2, a, b, c, d, P.ratio);
+        }
     }
     uint32_t info = GI_START | (v.counter & GI_COUNTER);
     if (v.emit) {
         info |= GI_EMIT;
-        if (contig) info |= GI_CONTIG;
+        if (w.contig) info |= GI_CONTIG;
         if (v.sA == '-') info |= GI_SA_MINUS;
         if (v.sB == '-') info |= GI_SB_MINUS;
-        st.g_posA[i] = v.posA; st.g_posB[i] = v.posB;
-        st.g_chrA[i] = v.chrA_off; st.g_chrB[i] = v.chrB_off;
-        st.g_chrA_len[i] = (uint16_t)v.chrA_len; st.g_chrB_len[i] = (uint16_t)v.chrB_len;
-        st.g_plen[i] = pair_line_len(ql, v);
-        st.g_slen[i] = P.write_sam ? (uint32_t)sam_bytes : 0u;
-        st.g_last_end[i] = last_end;
+        g.g_posA[i] = v.posA; g.g_posB[i] = v.posB;
+        g.g_chrA[i] = v.chrA_off; g.g_chrB[i] = v.chrB_off;
+        g.g_chrA_len[i] = (uint16_t)v.chrA_len; g.g_chrB_len[i] = (uint16_t)v.chrB_len;
+        g.g_plen[i] = pair_line_len(ql, v);
+        g.g_slen[i] = P.write_sam ? (uint32_t)w.sam_bytes : 0u;
+        g.g_last_end[i] = w.last_end;
     }
-    st.g_info[i] = info;
+    g.g_info[i] = info;
 }
 
-// ---- phase: emit the group opened by line i ----------------------------------------------------
-struct StageSink {
-    uint8_t* p;
-    MKT_HD void put(uint8_t c) { *p++ = c; }
-};
+// ---- phase: account for / emit the group opened by line i ---------------------------------------
 struct OutPtrs {
     uint8_t* pairs; uint64_t pairs_cap;
     uint8_t* sam; uint64_t sam_cap;
-    uint64_t* sc; uint64_t sc_cap;      // global indices of self-circle groups (quirk Q2)
-    uint64_t sc_base, group_base;       // totals of the blocks before this one
+    uint64_t* sc; uint64_t sc_cap;      // self-circle groups: (tile << 32 | ordinal in tile), resolved to global indices by k_finish
+    uint64_t sc_base;                   // entries written by the blocks before this one
 };
 
-template <class Cfg> MKT_HD void ph_emit(TileState<Cfg>& st, const TextView& tv, const Params& P, const OutPtrs& out, uint32_t i) {
-    const uint32_t info = st.g_info[i];
+// slow .sam copy: surviving lines of [first line, last member end), each followed by '\n'
+template <class Cfg> MKT_COLD void sam_copy_slow(TileState<Cfg>& st, const TextView& tv, const Params& P, const OutPtrs& out, uint32_t i) {
+    uint64_t go = st.base.sam_bytes + st.u.g.x_sam[i];
+    if (go + st.u.g.g_slen[i] > out.sam_cap) { lds_or(&st.err, E_SAM_CAP); return; }
+    uint32_t q = st.off[i];
+    const uint32_t stop = st.u.g.g_last_end[i];
+    while (q < stop) {
+        Rec r = parse_record(tv, q, P);
+        const uint32_t e = find_newline(tv, q);
+        if (r.survive && rec_in_range(r)) {
+            for (uint32_t p = q; p < e; ++p) out.sam[go++] = tv.at(p);
+            out.sam[go++] = '\n';
+        }
+        q = e + 1;
+    }
+}
+
+template <class Cfg> MKT_HD void ph_account(TileState<Cfg>& st, const TextView& tv, const Params& P, const OutPtrs& out, uint32_t tile, uint32_t i) {
+    const uint32_t info = st.u.g.g_info[i];
     if (!(info & GI_START)) return;
     const uint32_t counter = info & GI_COUNTER;
     if (counter) lds_add(&st.cnt[counter], 1u);
     if (counter == C_SELFCIRCLE) {
-        uint64_t k = out.sc_base + st.base.sc + st.x_sc[i];
-        if (k < out.sc_cap) out.sc[k] = out.group_base + st.base.groups + st.x_grp[i];
+        uint64_t k = out.sc_base + st.base.sc + st.u.g.x_sc[i];
+        if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
         else lds_or(&st.err, E_SC_CAP);
     }
-    if (!(info & GI_EMIT)) return;
+    if ((info & GI_EMIT) && P.write_sam && !(info & GI_CONTIG)) sam_copy_slow(st, tv, P, out, i);
+}
+
+// byte k (0 <= k < sums.pair_bytes) of the tile's .pairs output
+template <class Cfg> MKT_HD uint8_t tile_pair_byte(const TileState<Cfg>& st, const TextView& tv, uint32_t k) {
+    const auto& g = st.u.g;
+    uint32_t lo = 0, hi = st.sums.emitted;            // largest ordinal whose offset is <= k
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g.x_pair[g.em_idx[mid]] <= k) lo = mid; else hi = mid;
+    }
+    const uint32_t i = g.em_idx[lo];
+    const uint32_t info = g.g_info[i];
     Verdict v;
-    v.counter = counter; v.emit = true;
-    v.chrA_off = st.g_chrA[i]; v.chrA_len = st.g_chrA_len[i]; v.chrB_off = st.g_chrB[i]; v.chrB_len = st.g_chrB_len[i];
-    v.posA = st.g_posA[i]; v.posB = st.g_posB[i];
+    v.counter = info & GI_COUNTER; v.emit = true;
+    v.chrA_off = g.g_chrA[i]; v.chrA_len = g.g_chrA_len[i]; v.chrB_off = g.g_chrB[i]; v.chrB_len = g.g_chrB_len[i];
+    v.posA = g.g_posA[i]; v.posB = g.g_posB[i];
     v.sA = (info & GI_SA_MINUS) ? '-' : '+'; v.sB = (info & GI_SB_MINUS) ? '-' : '+';
-    const uint32_t qa = st.off[i] + st.qn_off[i], ql = st.qn_len[i];
-    const uint32_t lo = st.x_pair[i], len = st.g_plen[i];
-    if (lo + len <= (uint32_t)Cfg::STG) {
-        StageSink s{st.stg + lo};
-        format_pair(s, tv, qa, ql, v);
-        lds_max(&st.stg_used, lo + len);
-    } else {
-        uint64_t go = (uint64_t)st.base.pair_bytes + lo;
-        if (go + len <= out.pairs_cap) { StageSink s{out.pairs + go}; format_pair(s, tv, qa, ql, v); }
-        else lds_or(&st.err, E_PAIRS_CAP);
-    }
-    if (P.write_sam && !(info & GI_CONTIG)) {
-        // slow copy: surviving lines of [first line, last member end), each followed by '\n'
-        uint64_t go = st.base.sam_bytes + st.x_sam[i];
-        if (go + st.g_slen[i] > out.sam_cap) { lds_or(&st.err, E_SAM_CAP); return; }
-        uint32_t q = st.off[i];
-        const uint32_t stop = st.g_last_end[i];
-        while (q < stop) {
-            Rec r = parse_record(tv, q, P);
-            const uint32_t e = find_newline(tv, q);
-            bool s = r.survive && r.qn_off <= 0xFFFFu && r.qn_len <= 0xFFFFu && r.rn_off <= 0xFFFFu && r.rn_len <= 0xFFFFu;
-            if (s) {
-                for (uint32_t p = q; p < e; ++p) out.sam[go++] = tv.at(p);
-                out.sam[go++] = '\n';
-            }
-            q = e + 1;
-        }
-    }
+    return pair_line_byte(tv, st.off[i] + st.qn_off[i], st.qn_len[i], v, k - g.x_pair[i]);
 }
 
 // the tile's last group, for the host's Q1 bookkeeping
 template <class Cfg> MKT_HD void ph_last(const TileState<Cfg>& st, TileLast* tl, uint32_t i) {
-    const uint32_t info = st.g_info[i];
+    const auto& g = st.u.g;
+    const uint32_t info = g.g_info[i];
     if (!(info & GI_START)) return;
-    if ((uint32_t)st.x_grp[i] + 1u != st.sums.groups) return;
+    if ((uint32_t)g.x_grp[i] + 1u != st.sums.groups) return;
     tl->counter = info & GI_COUNTER;
-    tl->pair_bytes = st.g_plen[i];
-    tl->sam_bytes = st.g_slen[i];
+    tl->pair_bytes = g.g_plen[i];
+    tl->sam_bytes = g.g_slen[i];
+    tl->pair_off = st.base.pair_bytes + g.x_pair[i];
+    tl->sam_off = (uint32_t)(st.base.sam_bytes + g.x_sam[i]);
     tl->valid = 1;
 }
 

@@ -22,7 +22,8 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
     sam.assign((size_t)n + 4096, 0);
     const uint64_t sc_base = sc.size();
     sc.resize(sc_base + (size_t)n / 2 + 16, 0);
-    OutPtrs out{pairs.data(), pairs.size(), sam.data(), sam.size(), sc.data(), sc.size(), sc_base, group_base};
+    OutPtrs out{pairs.data(), pairs.size(), sam.data(), sam.size(), sc.data(), sc.size(), sc_base};
+    std::vector<uint32_t> tile_groups;
     std::unique_ptr<TileState<Cfg>> stp(new TileState<Cfg>);
     TileState<Cfg>& st = *stp;
     TileSums run = {0, 0, 0, 0, 0};
@@ -32,8 +33,14 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
         tile_reset(st);
         TileGeom G = tile_geom<Cfg>(t, n);
         const uint32_t wlen = G.w1 - G.w0;
+        memset(st.win, 0, sizeof st.win);
         memcpy(st.win, text + G.w0, wlen);
-        TextView tv{text, n, st.win, G.w0, wlen};
+        memset(&st.u, 0, sizeof st.u);
+        for (uint32_t r = 0; r < wlen; ++r) {
+            if (st.win[r] == '\n') st.u.m.nlm[r >> 6] |= 1ull << (r & 63);
+            if (is_ws(st.win[r])) st.u.m.wsm[r >> 6] |= 1ull << (r & 63);
+        }
+        TextView tv = tile_view(st, text, n, G);
         // line table
         uint32_t NL = 0;
         bool overflow = false;
@@ -43,31 +50,36 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
         if (overflow) { st.err |= E_LINE_TABLE; NL = 0; }
         st.NL = NL; st.first_idx = NL; st.end_idx = NL;
         for (uint32_t i = 0; i < NL; ++i) ph_parse(st, tv, P, G, i);
-        for (uint32_t i = st.first_idx; i < NL; ++i) ph_start(st, tv, P, i);
+        tile_trim(st);
+        NL = st.NL;
         for (uint32_t i = st.first_idx; i < st.end_idx; ++i) ph_group(st, tv, P, G, i);
         // exclusive sums
         TileSums s = {0, 0, 0, 0, 0};
         for (uint32_t i = st.first_idx; i < st.end_idx; ++i) {
-            const uint32_t info = st.g_info[i];
-            st.x_grp[i] = (uint16_t)s.groups; st.x_emit[i] = (uint16_t)s.emitted; st.x_sc[i] = (uint16_t)s.sc;
-            st.x_pair[i] = s.pair_bytes; st.x_sam[i] = (uint32_t)s.sam_bytes;
+            auto& g = st.u.g;
+            const uint32_t info = g.g_info[i];
+            g.x_grp[i] = (uint16_t)s.groups; g.x_sc[i] = (uint16_t)s.sc;
+            g.x_pair[i] = s.pair_bytes; g.x_sam[i] = (uint32_t)s.sam_bytes;
+            if (info & GI_EMIT) g.em_idx[s.emitted] = (uint16_t)i;
             if (info & GI_START) ++s.groups;
             if (info & GI_EMIT) ++s.emitted;
             if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ++s.sc;
-            s.pair_bytes += st.g_plen[i]; s.sam_bytes += st.g_slen[i];
+            s.pair_bytes += g.g_plen[i]; s.sam_bytes += g.g_slen[i];
         }
         st.sums = s; st.base = run;
-        for (uint32_t i = st.first_idx; i < st.end_idx; ++i) ph_emit(st, tv, P, out, i);
-        if (run.pair_bytes + (uint64_t)st.stg_used <= out.pairs_cap) memcpy(out.pairs + run.pair_bytes, st.stg, st.stg_used);
-        else st.err |= E_PAIRS_CAP;
+        tile_groups.push_back(run.groups);      // exclusive prefix, as k_finish computes it
+        for (uint32_t i = st.first_idx; i < st.end_idx; ++i) ph_account(st, tv, P, out, t, i);
+        if (run.pair_bytes + (uint64_t)s.pair_bytes <= out.pairs_cap) {
+            for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = tile_pair_byte(st, tv, k);
+        } else st.err |= E_PAIRS_CAP;
         if (P.write_sam)
             for (uint32_t i = st.first_idx; i < st.end_idx; ++i)
-                if ((st.g_info[i] & GI_EMIT) && (st.g_info[i] & GI_CONTIG)) {
-                    uint64_t go = run.sam_bytes + st.x_sam[i];
-                    if (go + st.g_slen[i] <= out.sam_cap) memcpy(out.sam + go, text + st.off[i], st.g_slen[i]);
+                if ((st.u.g.g_info[i] & GI_EMIT) && (st.u.g.g_info[i] & GI_CONTIG)) {
+                    uint64_t go = run.sam_bytes + st.u.g.x_sam[i];
+                    if (go + st.u.g.g_slen[i] <= out.sam_cap) memcpy(out.sam + go, text + st.off[i], st.u.g.g_slen[i]);
                     else st.err |= E_SAM_CAP;
                 }
-        TileLast tl = {0, 0, 0, 0};
+        TileLast tl = {0, 0, 0, 0, 0, 0};
         for (uint32_t i = st.first_idx; i < st.end_idx; ++i) ph_last(st, &tl, i);
         if (tl.valid) res.last = tl;
         for (int c = 0; c < (int)C_COUNT; ++c) res.counters[c] += st.cnt[c];
@@ -75,25 +87,31 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
         run.groups += s.groups; run.emitted += s.emitted; run.sc += s.sc; run.pair_bytes += s.pair_bytes; run.sam_bytes += s.sam_bytes;
     }
     res.groups = run.groups; res.emitted = run.emitted; res.sc = run.sc; res.pair_bytes = run.pair_bytes; res.sam_bytes = run.sam_bytes;
+    for (uint64_t k = 0; k < run.sc; ++k) {       // what k_finish does: (tile, ordinal) -> global group index
+        const uint64_t e = sc[sc_base + k];
+        sc[sc_base + k] = group_base + tile_groups[(uint32_t)(e >> 32)] + (uint32_t)(e & 0xFFFFFFFFu);
+    }
     pairs.resize(run.pair_bytes); sam.resize(run.sam_bytes); sc.resize(sc_base + run.sc);
 }
 
-typedef TileCfg<16384, 1024, 4096, 256, 4, 4096> CfgFast;
-typedef TileCfg<256, 64, 192, 512, 4, 512> CfgSafe;
-typedef TileCfg<1024, 128, 512, 96, 4, 256> CfgMid;
-typedef TileCfg<2048, 16, 16, 128, 4, 64> CfgNoHalo;
+typedef TileCfg<16384, 2048, 4096, 256, 4> CfgFast;
+typedef TileCfg<256, 64, 192, 512, 4> CfgSafe;
+typedef TileCfg<1024, 128, 512, 96, 4> CfgMid;
+typedef TileCfg<2048, 16, 16, 128, 4> CfgNoHalo;
 
-extern "C" {
-// Returns 0 on success.  out_* are malloc'ed; caller frees with emul_free.  log must hold >= 256 bytes.
-int emul_run(const char* text, size_t n, int mode, float ratio, int min_mapq, int write_sam, int ref_threads, int cfg,
-             size_t block_bytes, char** out_pairs, size_t* n_pairs, char** out_sam, size_t* n_sam, char* log,
-             uint64_t* stats /* groups, pairs, err, blocks */) {
-    Params P{mode, ratio, (uint32_t)min_mapq, write_sam};
+// One emulated shard / input stream (mirrors a mkt_ctx of the library: feed, group count, finish).
+struct EmulShard {
+    Params P;
+    int ref_threads, cfg;
     RunAccum acc;
-    std::vector<uint8_t> all_pairs, all_sam, bp, bs;
+    std::vector<uint8_t> pairs, sam;
     std::vector<uint64_t> sc;
     uint32_t err = 0;
     uint64_t blocks = 0;
+};
+
+static void emul_feed(EmulShard& S, const char* text, size_t n, size_t block_bytes) {
+    std::vector<uint8_t> bp, bs;
     size_t pos = 0;
     if (block_bytes == 0) block_bytes = n ? n : 1;
     while (pos < n) {
@@ -109,26 +127,58 @@ int emul_run(const char* text, size_t n, int mode, float ratio, int min_mapq, in
         }
         BlockResult r;
         const uint8_t* b = (const uint8_t*)text + pos;
-        switch (cfg) {
-        case 1: emul_block<CfgSafe>(b, (uint32_t)take, P, bp, bs, sc, acc.groups, r); break;
-        case 2: emul_block<CfgMid>(b, (uint32_t)take, P, bp, bs, sc, acc.groups, r); break;
-        case 3: emul_block<CfgNoHalo>(b, (uint32_t)take, P, bp, bs, sc, acc.groups, r); break;
-        default: emul_block<CfgFast>(b, (uint32_t)take, P, bp, bs, sc, acc.groups, r); break;
+        switch (S.cfg) {
+        case 1: emul_block<CfgSafe>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
+        case 2: emul_block<CfgMid>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
+        case 3: emul_block<CfgNoHalo>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
+        default: emul_block<CfgFast>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
         }
-        err |= r.err;
-        acc.add_block(r);
-        all_pairs.insert(all_pairs.end(), bp.begin(), bp.end());
-        all_sam.insert(all_sam.end(), bs.begin(), bs.end());
+        S.err |= r.err;
+        S.acc.add_block(r);
+        S.pairs.insert(S.pairs.end(), bp.begin(), bp.end());
+        S.sam.insert(S.sam.end(), bs.begin(), bs.end());
         pos += take;
-        ++blocks;
+        ++S.blocks;
     }
-    RunStats s = acc.finish(true, (uint32_t)ref_threads, 0, acc.groups, sc.data());
-    all_pairs.resize(s.pair_bytes);
-    all_sam.resize(s.sam_bytes);
-    *out_pairs = (char*)malloc(all_pairs.size() + 1); memcpy(*out_pairs, all_pairs.data(), all_pairs.size()); *n_pairs = all_pairs.size();
-    *out_sam = (char*)malloc(all_sam.size() + 1); memcpy(*out_sam, all_sam.data(), all_sam.size()); *n_sam = all_sam.size();
-    format_log(s, log, 256);
-    stats[0] = s.groups; stats[1] = s.pairs; stats[2] = err; stats[3] = blocks;
+}
+
+extern "C" {
+void* emul_open(int mode, float ratio, int min_mapq, int write_sam, int ref_threads, int cfg) {
+    EmulShard* S = new EmulShard();
+    S->P = Params{mode, ratio, (uint32_t)min_mapq, write_sam};
+    S->ref_threads = ref_threads; S->cfg = cfg;
+    return S;
+}
+void emul_feed_bytes(void* h, const char* text, size_t n, size_t block_bytes) { emul_feed(*(EmulShard*)h, text, n, block_bytes); }
+uint64_t emul_groups(void* h) { return ((EmulShard*)h)->acc.groups; }
+// counters8: lowMap manyHits unpaired selfCircle trans cis10K cis1K cis0 ; stats: groups, pairs, err, blocks
+int emul_finish(void* h, int drop_last, uint64_t group_offset, uint64_t total_groups, char** out_pairs, size_t* n_pairs,
+                char** out_sam, size_t* n_sam, uint32_t* counters8, uint64_t* stats) {
+    EmulShard& S = *(EmulShard*)h;
+    RunStats s = S.acc.finish(drop_last != 0, (uint32_t)S.ref_threads, group_offset, total_groups ? total_groups : S.acc.groups, S.sc.data());
+    // the dropped group's bytes are the tail of the (input-ordered) emulation output
+    S.pairs.resize(s.pair_bytes);
+    S.sam.resize(s.sam_bytes);
+    *out_pairs = (char*)malloc(S.pairs.size() + 1); memcpy(*out_pairs, S.pairs.data(), S.pairs.size()); *n_pairs = S.pairs.size();
+    *out_sam = (char*)malloc(S.sam.size() + 1); memcpy(*out_sam, S.sam.data(), S.sam.size()); *n_sam = S.sam.size();
+    const int order[8] = {C_LOWMAP, C_MANYHITS, C_UNPAIRED, C_SELFCIRCLE, C_TRANS, C_CIS10K, C_CIS1K, C_CIS0};
+    for (int k = 0; k < 8; ++k) counters8[k] = s.counters[order[k]];
+    stats[0] = s.groups; stats[1] = s.pairs; stats[2] = S.err; stats[3] = S.blocks;
+    return 0;
+}
+void emul_close(void* h) { delete (EmulShard*)h; }
+
+// whole input in one call (single stream)
+int emul_run(const char* text, size_t n, int mode, float ratio, int min_mapq, int write_sam, int ref_threads, int cfg,
+             size_t block_bytes, char** out_pairs, size_t* n_pairs, char** out_sam, size_t* n_sam, char* log,
+             uint64_t* stats /* groups, pairs, err, blocks */) {
+    void* h = emul_open(mode, ratio, min_mapq, write_sam, ref_threads, cfg);
+    emul_feed_bytes(h, text, n, block_bytes);
+    uint32_t c8[8];
+    emul_finish(h, 1, 0, 0, out_pairs, n_pairs, out_sam, n_sam, c8, stats);
+    snprintf(log, 256, "lowMap\t%u\nmanyHits\t%u\nunpaired\t%u\nselfCircle\t%u\ntrans\t%u\ncis10K\t%u\ncis1K\t%u\ncis0\t%u\n",
+             c8[0], c8[1], c8[2], c8[3], c8[4], c8[5], c8[6], c8[7]);
+    emul_close(h);
     return 0;
 }
 void emul_free(void* p) { free(p); }

@@ -1,0 +1,79 @@
+"""The C-ABI library: loads, exports every symbol include/mkt.h declares, and refuses to run without a GPU.
+The drop-in executable: argv handling and exit codes of the reference (sam2pairs.cpp:24-91) that do not need a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+import microcket_amd as m
+import util
+
+ROOT = util.ROOT
+
+
+def _built_lib():
+    if not os.path.exists(m.lib_path()):
+        from microcket_amd import build
+        build.build_lib()
+        build.build_exe()
+    return m.lib_path()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_built_lib())
+    hdr = open(os.path.join(ROOT, "include", "mkt.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(mkt_[a-z_0-9]+)\s*\(", hdr)))
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mkt.h but not exported"
+    assert lib.mkt_abi_version() == 1
+    # and the Python binding lists the same entry points
+    from microcket_amd import capi
+    assert set(capi.EXPORTS) == set(names)
+
+
+@pytest.mark.skipif(m.device_count() > 0 if os.path.exists(m.lib_path()) else False, reason="a GPU is present")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    _built_lib()
+    with pytest.raises(m.MktError) as e:
+        m.Context("unc")
+    assert "no" in str(e.value).lower() and "cpu" in str(e.value).lower()
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    """oracle/ is test infrastructure: nothing under microcket_amd/ or include/ may reference it."""
+    for base in ("microcket_amd", "include"):
+        for dp, dn, fn in os.walk(os.path.join(ROOT, base)):
+            for f in fn:
+                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if f == "build.py":
+                        txt = txt.replace("build_oracle", "")       # the builder compiles the checker; it does not use it
+                    assert "liboracle" not in txt and "sam2pairs_oracle" not in txt and "orc_run" not in txt, os.path.join(dp, f)
+    out = subprocess.run(["ldd", _built_lib()], stdout=subprocess.PIPE).stdout.decode()
+    assert "oracle" not in out
+
+
+def test_executable_exit_codes_without_gpu(tmp_path):
+    _built_lib()
+    exe = m.exe_path()
+    sam = tmp_path / "x.sam"
+    sam.write_bytes(util.synth("unc", 1, 10))
+    r = subprocess.run([exe], stderr=subprocess.PIPE)
+    assert r.returncode == 2 and b"Usage" in r.stderr                                   # sam2pairs.cpp:24-31
+    r = subprocess.run([exe, str(sam), "unc", str(tmp_path / "o"), "1"], stderr=subprocess.PIPE)
+    assert r.returncode == 5 and b"at least 2 threads" in r.stderr                      # :36-39
+    r = subprocess.run([exe, str(sam), "bad", str(tmp_path / "o"), "4", "0.5", "10", "no"], stderr=subprocess.PIPE)
+    assert r.returncode == 6                                                            # :64-67
+    assert b"INFO: min_mapped_ratio is set to 0.5." in r.stderr and b"INFO: min_mapQ is set to 10." in r.stderr
+    assert b"WARN: sam output is skipped." in r.stderr                                  # :42,45,49
+    r = subprocess.run([exe, str(tmp_path / "missing.sam"), "unc", str(tmp_path / "o"), "4"], stderr=subprocess.PIPE)
+    assert r.returncode == 10                                                           # :70-75
+    r = subprocess.run([exe, str(sam), "unc", str(tmp_path / "nodir" / "o"), "4"], stderr=subprocess.PIPE)
+    assert r.returncode == 11                                                           # :82-91
+    if m.device_count() == 0:
+        r = subprocess.run([exe, str(sam), "unc", str(tmp_path / "o"), "4"], stderr=subprocess.PIPE, stdout=subprocess.PIPE)
+        assert r.returncode == 20 and r.stdout == b""                                   # no GPU: loud failure, no output

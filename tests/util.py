@@ -141,3 +141,53 @@ def emul_run(text, mode, threads=4, ratio=0.5, mapq=10, sam=True, cfg=0, block=0
     _emul.emul_free(op)
     _emul.emul_free(osam)
     return pairs, s, log.value, {"groups": st[0], "pairs": st[1], "err": st[2], "blocks": st[3]}
+
+
+class EmulShard:
+    """Test stand-in for microcket_amd.Context on a machine without a GPU: same tile phases, run on the CPU."""
+
+    class St:
+        pass
+
+    def __init__(self, mode, ratio=0.5, mapq=10, sam=True, threads=4, cfg=0):
+        global _emul
+        ensure_built()
+        if _emul is None:
+            _emul = C.CDLL(EMUL_SO)
+        _emul.emul_open.restype = C.c_void_p
+        _emul.emul_groups.restype = C.c_uint64
+        _emul.emul_groups.argtypes = [C.c_void_p]
+        _emul.emul_feed_bytes.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t]
+        _emul.emul_finish.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        _emul.emul_close.argtypes = [C.c_void_p]
+        if isinstance(mode, str):
+            mode = MODES[mode]
+        self.h = C.c_void_p(_emul.emul_open(mode, C.c_float(ratio), mapq, 1 if sam else 0, threads, cfg))
+
+    def feed(self, text, block=0):
+        _emul.emul_feed_bytes(self.h, text, len(text), block)
+
+    def group_count(self):
+        return int(_emul.emul_groups(self.h))
+
+    def finish(self, drop_last=True, group_offset=0, total_groups=0):
+        op, osam = C.c_void_p(), C.c_void_p()
+        npairs, nsam = C.c_size_t(), C.c_size_t()
+        c8 = (C.c_uint32 * 8)()
+        st = (C.c_uint64 * 4)()
+        _emul.emul_finish(self.h, 1 if drop_last else 0, group_offset, total_groups, C.byref(op), C.byref(npairs), C.byref(osam), C.byref(nsam), c8, st)
+        r = EmulShard.St()
+        r.pairs_bytes = C.string_at(op, npairs.value)
+        r.sam_bytes = C.string_at(osam, nsam.value)
+        _emul.emul_free(op)
+        _emul.emul_free(osam)
+        for k, name in enumerate(("lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0")):
+            setattr(r, name, int(c8[k]))
+        r.groups, r.pairs, r.err = int(st[0]), int(st[1]), int(st[2])
+        return r
+
+    def close(self):
+        if self.h:
+            _emul.emul_close(self.h)
+            self.h = None
