@@ -1,0 +1,239 @@
+"""GPU parity tests (run on the MI355X box: python -m pytest tests -m gpu).
+
+Everything goes through the C ABI of include/mkt.h (ctypes) or through the drop-in executable;
+the oracle / the reference build are only the CHECKER.  Bit-exact bar: .log byte-identical;
+stdout and .sam byte-identical in input order (ordered=True) or after the driver's own canonical
+sort (default any-order mode -- the reference's order is thread-schedule dependent too)."""
+import os
+
+import numpy as np
+import pytest
+
+import microcket_amd as m
+import util
+
+pytestmark = pytest.mark.gpu
+
+GRID = [(4, 0.5, 10, True), (2, 0.8, 30, True), (8, 0.5, 0, False), (3, 0.5, 10, True)]
+
+
+def _need_gpu():
+    if m.device_count() < 1:
+        pytest.fail("no HIP device: the HIP path is the only path (no CPU fallback to test)")
+
+
+def _run(text, mode, T, ratio, mapq, sam, tiles=m.TILES_AUTO, ordered=False, block=0, chunk=1 << 20):
+    with m.Context(mode, ratio, mapq, sam, T, device=0, block_bytes=block, tiles=tiles, ordered=ordered) as c:
+        return c.run_bytes(text, chunk=chunk)
+
+
+def _check(text, mode, T, ratio, mapq, sam, **kw):
+    po, so, lo, st = util.oracle_run(text, mode, T, ratio, mapq, sam)
+    p, s, stats, log = _run(text, mode, T, ratio, mapq, sam, **kw)
+    tag = (mode, T, ratio, mapq, sam, kw)
+    assert log == lo, tag
+    assert stats.groups == st.groups and stats.pairs == st.pairs, tag
+    if kw.get("ordered"):
+        assert p == po and s == so, tag
+    else:
+        assert util.canon(p) == util.canon(po) and util.canon(s) == util.canon(so), tag
+
+
+def test_golden_vectors_through_the_c_abi(golden):
+    """Every golden vector (outputs of the reference itself) reproduced by the HIP path."""
+    _need_gpu()
+    for ent in golden["inputs"]:
+        if ent["kind"] == "file":
+            text = open(os.path.join(util.GOLDEN, ent["name"]), "rb").read()
+        else:
+            text = util.synth(ent["profile"], ent["seed"], ent["groups"], ent["read_len"], ent["genome"], ent["lanes"], 1)
+        assert util.sha(text) == ent["sha256"]
+        for c in ent["cases"]:
+            p, s, stats, log = _run(text, c["mode"], c["threads"], c["ratio"], c["mapq"], c["sam"])
+            cp, cs = util.canon(p), util.canon(s)
+            tag = (ent["name"], c["mode"], c["threads"], c["ratio"], c["mapq"], c["sam"])
+            assert log.decode() == c["log"], tag
+            assert util.sha(cp) == c["pairs_sha256"] and cp.count(b"\n") == c["pairs_lines"], tag
+            assert util.sha(cs) == c["sam_sha256"], tag
+
+
+@pytest.mark.parametrize("tiles,ordered", [(m.TILES_FAST, True), (m.TILES_FAST, False), (m.TILES_SMALL, True)])
+@pytest.mark.parametrize("profile,seed,groups,modes", [
+    ("unc", 21, 6000, ("unc",)), ("flash", 22, 6000, ("flash",)), ("stress", 23, 12000, ("unc", "flash")),
+])
+def test_synthetic_sets_vs_oracle(profile, seed, groups, modes, tiles, ordered):
+    _need_gpu()
+    text = util.synth(profile, seed, groups)
+    for mode in modes:
+        for (T, ratio, mapq, sam) in GRID:
+            for block in (0, 1 << 17):
+                _check(text, mode, T, ratio, mapq, sam, tiles=tiles, ordered=ordered, block=block, chunk=70001)
+
+
+@pytest.mark.parametrize("name", ["edge_unc.sam", "edge_flash.sam"])
+def test_edge_fixtures_vs_oracle(name):
+    _need_gpu()
+    text = open(os.path.join(util.GOLDEN, name), "rb").read()
+    for mode in ("unc", "flash"):
+        for (T, ratio, mapq, sam) in GRID:
+            for tiles in (m.TILES_FAST, m.TILES_SMALL):
+                _check(text, mode, T, ratio, mapq, sam, tiles=tiles, ordered=True, block=4096, chunk=777)
+
+
+def test_ragged_inputs():
+    _need_gpu()
+    base = util.synth("unc", 5, 200, tail=1)
+    for text in (b"", b"\n\n", b"@HD\tVN:1.6\n", b"junk line without tabs\n", base[:-1], base.replace(b"\n", b"\r\n"),
+                 base + b"@late\theader\n", b"\n" + base):
+        _check(text, "unc", 4, 0.5, 10, True, ordered=True)
+        _check(text, "flash", 4, 0.5, 10, True, tiles=m.TILES_SMALL, ordered=True)
+
+
+def test_tiny_lines_overflow_the_line_table_and_fall_back():
+    """Lines of ~35 bytes put more line starts into a window than the fast config's table holds: AUTO re-runs the
+    block with the small-tile config; forcing the fast config fails loudly instead of returning wrong results."""
+    _need_gpu()
+    rows = []
+    for g in range(4000):
+        rows.append(f"r{g}\t65\tchr1\t{1000 + g}\t60\t5M\t=\t1\t0\tA\tF\n")
+        rows.append(f"r{g}\t129\tchr1\t{9000 + 3 * g}\t60\t5M\t=\t1\t0\tA\tF\n")
+    text = "".join(rows).encode()
+    _check(text, "unc", 4, 0.5, 10, True, tiles=m.TILES_AUTO)
+    with pytest.raises(m.MktError):
+        _run(text, "unc", 4, 0.5, 10, True, tiles=m.TILES_FAST)
+
+
+def test_executable_is_a_drop_in(tmp_path):
+    """Same argv, stdout, side files and stderr messages as the reference binary (when present) / the oracle."""
+    _need_gpu()
+    exe = m.exe_path()
+    for profile, mode in (("unc", "unc"), ("flash", "flash"), ("stress", "unc")):
+        text = util.synth(profile, 41, 5000)
+        for (T, ratio, mapq, sam) in ((4, 0.5, 10, True), (8, 0.8, 20, False)):
+            rc, out, s, log, err = util.cli_run(exe, text, mode, T, ratio, mapq, sam, env={"MKT_BLOCK_MB": "1"})
+            assert rc == 0, err
+            if util.have_ref():
+                rrc, rout, rs, rlog, rerr = util.ref_run(text, mode, T, ratio, mapq, sam)
+                assert rerr == err                       # INFO / WARN lines, byte for byte
+            else:
+                rout, rs, rlog, _ = util.oracle_run(text, mode, T, ratio, mapq, sam)
+            assert log == rlog
+            assert util.canon(out) == util.canon(rout)
+            assert util.canon(s) == util.canon(rs)
+    # stdin, as the driver calls it (microcket:479): bwa | sam2pairs /dev/stdin ...
+    import subprocess
+    text = util.synth("unc", 43, 3000)
+    p = subprocess.run([exe, "/dev/stdin", "unc", str(tmp_path / "o"), "4", "0.5", "10", "no"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    po, so, lo, st = util.oracle_run(text, "unc", 4, 0.5, 10, False)
+    assert p.returncode == 0 and util.canon(p.stdout) == util.canon(po)
+    assert (tmp_path / "o.unc2pairs.log").read_bytes() == lo and not (tmp_path / "o.unc.sam").exists()
+
+
+def test_device_generator_equals_host_generator():
+    _need_gpu()
+    with m.Context("unc", device=0) as c:
+        for prof, pid in (("unc", 0), ("flash", 1), ("stress", 2)):
+            d, n = c.synth_device(77, pid, 3000, first_group=123, tail_group=True)
+            assert c.copy_to_host(d, n) == util.synth(prof, 77, 3000, tail=1, first=123), prof
+
+
+def test_resident_path_multi_block_and_q2_across_batches():
+    """K > 2^18 surviving groups, device-resident blocks: the logged selfCircle must follow the closed form (quirk Q2)."""
+    _need_gpu()
+    n = (1 << 18) + (1 << 17) + 12345
+    for T in (2, 8):
+        with m.Context("unc", 0.5, 0, False, T, device=0) as c:
+            ds = c.dataset(99, 0, n, 1 << 16, read_len=50, tail_group=True)
+            host = b"".join(c.copy_to_host(p, nb) for (p, nb, g) in ds.blocks)
+            for (p, nb, g) in ds.blocks:
+                c.submit_device(p, nb)
+            st = c.finish(True)
+            ds.close()
+        po, so, lo, ost = util.oracle_run(host, "unc", T, 0.5, 0, False)
+        assert c.format_log(st) == lo, (T, c.format_log(st), lo)
+        assert st.groups == ost.groups and st.pairs == ost.pairs
+
+
+def test_two_contexts_as_two_shards():
+    """The sharded bookkeeping (group offsets, Q1 on the last shard only) with real kernels: 2 contexts on one GPU."""
+    _need_gpu()
+    from microcket_amd import shard
+    text = util.synth("stress", 51, 8000)
+    cuts = shard.cut_points(text, 2)
+    po, so, lo, ost = util.oracle_run(text, "unc", 4, 0.5, 10, True)
+    ctxs = [m.Context("unc", 0.5, 10, True, 4, device=0, block_bytes=1 << 18, ordered=True) for _ in range(2)]
+    outs = []
+    for r, c in enumerate(ctxs):
+        c.submit(text[cuts[r]:cuts[r + 1]], last=True)
+    counts = [c.group_count() for c in ctxs]
+    total = sum(counts)
+    sums = [0] * 8
+    pairs, sam = b"", b""
+    for r, c in enumerate(ctxs):
+        a, b = c.drain()
+        st = c.finish(drop_last=(r == 1), group_offset=sum(counts[:r]), total_groups=total)
+        a2, b2 = c.drain()
+        pairs += a + a2
+        sam += b + b2
+        for k, name in enumerate(shard.COUNTERS):
+            sums[k] += getattr(st, name)
+        c.close()
+    assert pairs == po and sam == so
+    assert shard.format_log(dict(zip(shard.COUNTERS, sums))) == lo
+
+
+def _line_multiset_checksum(buf: bytes) -> int:
+    """Order-independent 64-bit checksum of the lines of buf (vectorised polynomial hash per line, summed)."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    if a.size == 0:
+        return 0
+    nl = np.flatnonzero(a == 10)
+    starts = np.concatenate(([0], nl[:-1] + 1)) if nl.size else np.array([0])
+    line_id = np.zeros(a.size, dtype=np.int64)
+    line_id[starts[1:]] = 1
+    line_id = np.cumsum(line_id)
+    pos = np.arange(a.size, dtype=np.int64) - starts[line_id]
+    P = np.empty(int(pos.max()) + 1, dtype=np.uint64)
+    P[0] = 1
+    for i in range(1, P.size):
+        P[i] = (int(P[i - 1]) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    with np.errstate(over="ignore"):
+        w = (a.astype(np.uint64) + np.uint64(1)) * P[pos]
+        h = np.add.reduceat(w, starts)
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0x9E3779B97F4A7C15)
+        return int(h.sum(dtype=np.uint64))
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[1] size (100 M pairs, ~92 GB resident): size-independent properties.
+      * pairs == trans + cis10K + cis1K + cis0 (every emitting counter emits exactly one line);
+      * idempotence: a second pass gives identical statistics;
+      * block-cut independence on a 4 M-pair slice: different block sizes and tile configs give the
+        same multiset of output lines (order-independent checksum) as the CPU oracle on that slice."""
+    _need_gpu()
+    pairs = int(os.environ.get("MKT_TEST_FULL_PAIRS", 100_000_000))
+    with m.Context("unc", 0.5, 10, False, 8, device=0, tiles=m.TILES_FAST) as c:
+        ds = c.dataset(20260105, 0, pairs, 1 << 19, tail_group=True)
+        stats = []
+        for _ in range(2):
+            c.reset()
+            for (p, nb, g) in ds.blocks:
+                c.submit_device(p, nb)
+            stats.append(c.finish(True))
+        a, b = stats
+        assert a.counters() == b.counters() and a.pairs == b.pairs and a.pair_bytes == b.pair_bytes and a.groups == b.groups
+        assert a.pairs == a.trans + a.cis10K + a.cis1K + a.cis0
+        assert a.groups <= ds.total_groups and a.groups > 0.9 * ds.total_groups
+        assert a.bytes_in == ds.total_bytes
+        # slice: first 8 blocks (4 M pairs) against the oracle, by line-multiset checksum
+        nblk = min(8, ds.n_blocks)
+        host = b"".join(c.copy_to_host(p, nb) for (p, nb, g) in ds.blocks[:nblk])
+        ds.close()
+    po, so, lo, ost = util.oracle_run(host, "unc", 8, 0.5, 10, False)
+    want = _line_multiset_checksum(po)
+    for tiles, block in ((m.TILES_FAST, 0), (m.TILES_FAST, 64 << 20)):
+        with m.Context("unc", 0.5, 10, False, 8, device=0, block_bytes=block, tiles=tiles) as c:
+            p, s, st, log = c.run_bytes(host, chunk=256 << 20)
+        assert log == lo
+        assert len(p) == len(po) and _line_multiset_checksum(p) == want
