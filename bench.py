@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--sam", default="no", choices=["no", "yes"])
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))

@@ -40,6 +40,8 @@ struct mkt_ctx {
     bool input_done = false, finished = false;
     uint64_t bytes_in = 0, blocks = 0;
     size_t last_n = 0;                   // bytes of the last resident block
+    uint64_t sc_on_device = 0;           // self-circle entries of folded blocks still in d_sc
+    uint64_t bytes_unsynced = 0;         // resident bytes enqueued since the last sync
     // timing
     std::vector<hipEvent_t> ev;          // start/stop pairs of the tile kernel
     std::vector<uint64_t> ev_bytes;
@@ -178,7 +180,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, n / 3 + 65536))) return rc;
     if (c->P.write_sam && (rc = ensure_dev(c, &c->d_sam, &c->sam_cap, n + 64))) return rc;
     if (!c->d_sc) {
-        size_t need = (size_t)1 << 22;          // 4 Mi self-circle indices; grown at sync if exceeded
+        size_t need = (size_t)1 << 25;          // 32 Mi self-circle indices between two drains (256 MiB)
         HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
         c->sc_cap = need;
     }
@@ -226,6 +228,19 @@ static void fold_timing(mkt_ctx* c) {       // stream must be idle
     c->ev.clear(); c->ev_bytes.clear();
 }
 
+// stream idle: move the resolved self-circle indices of the folded blocks to the host, rewind the device list
+static int drain_sc(mkt_ctx* c) {
+    if (c->sc_on_device) {
+        const size_t old = c->sc_host.size();
+        c->sc_host.resize(old + (size_t)c->sc_on_device);
+        HIPCHK(c, hipMemcpy(c->sc_host.data() + old, c->d_sc, (size_t)c->sc_on_device * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        c->sc_on_device = 0;
+    }
+    if (c->d_run) HIPCHK(c, hipMemsetAsync(&c->d_run->sc, 0, sizeof(uint64_t), c->stream));
+    c->bytes_unsynced = 0;
+    return MKT_OK;
+}
+
 static int check_result(mkt_ctx* c, const BlockResult& r) {
     if (r.err == 0) return MKT_OK;
     return fail(c, MKT_E_KERNEL, "kernel error bits 0x%x%s%s%s%s%s%s", r.err,
@@ -253,19 +268,20 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         bool grew = false;
         if (r.err & E_PAIRS_CAP) { if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, r.pair_bytes + 4096))) return rc; grew = true; }
         if (r.err & E_SAM_CAP) { if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, r.sam_bytes + 4096))) return rc; grew = true; }
-        if (r.err & E_SC_CAP) {
-            size_t need = (size_t)(c->acc.sc + r.sc) * 2 + 4096;
-            uint64_t* nd = nullptr;
-            HIPCHK(c, hipMalloc((void**)&nd, need * sizeof(uint64_t)));
-            HIPCHK(c, hipMemcpy(nd, c->d_sc, (size_t)c->acc.sc * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+        if (r.err & E_SC_CAP) {            // the list is drained after every host block: it only has to hold this block's
+            size_t need = (size_t)r.sc * 2 + 4096;
             HIPCHK(c, hipFree(c->d_sc));
-            c->d_sc = nd; c->sc_cap = need; grew = true;
+            c->d_sc = nullptr; c->sc_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
+            c->sc_cap = need; grew = true;
         }
         if (!grew) return check_result(c, r);
     }
     // fetch outputs
     c->acc.add_block(r);
     ++c->blocks;
+    c->sc_on_device += r.sc;
+    if ((rc = drain_sc(c))) return rc;
     size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
     if (c->h_stage.size() < pb + sb) c->h_stage.resize(pb + sb);
     if (pb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data(), c->d_pairs, pb, hipMemcpyDeviceToHost, c->stream));
@@ -336,7 +352,9 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     if (c->finished) return fail(c, MKT_E_STATE, "submit after finish");
     if (!d_text && n) return fail(c, MKT_E_ARG, "null device pointer");
     HIPCHK(c, hipSetDevice(c->p.device));
-    if (c->res_used == c->res_slots) { int rc = mkt_sync(c); if (rc) return rc; }
+    // self-circle entries pile up on the device between syncs: at most one group per 64 input bytes is assumed
+    if (c->res_used == c->res_slots || (c->sc_cap && (c->bytes_unsynced + n) / 64 > c->sc_cap)) { int rc = mkt_sync(c); if (rc) return rc; }
+    c->bytes_unsynced += n;
     int rc = enqueue_block(c, (const uint8_t*)d_text, n, c->cfg, c->res_used);
     if (rc) return rc;
     ++c->res_used;
@@ -355,9 +373,11 @@ int mkt_sync(mkt_ctx* c) {
         const BlockResult& r = c->h_res[k];
         if (r.err) { rc = check_result(c, r); break; }      // resident blocks are not retried: fail loudly
         c->acc.add_block(r);
+        c->sc_on_device += r.sc;
         ++c->blocks;
     }
     c->res_used = 0; c->res_folded = 0;
+    if (rc == MKT_OK) rc = drain_sc(c);
     return rc;
 }
 
@@ -387,8 +407,7 @@ int mkt_finish(mkt_ctx* c, int drop_last, uint64_t group_offset, uint64_t total_
     if (!c || !st) return MKT_E_ARG;
     int rc = mkt_sync(c);
     if (rc) return rc;
-    c->sc_host.resize((size_t)c->acc.sc);
-    if (c->acc.sc) HIPCHK(c, hipMemcpy(c->sc_host.data(), c->d_sc, (size_t)c->acc.sc * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (c->sc_host.size() != c->acc.sc) return fail(c, MKT_E_STATE, "self-circle list out of step (%zu vs %llu)", c->sc_host.size(), (unsigned long long)c->acc.sc);
     const uint64_t K = total_groups ? total_groups : c->acc.groups;
     RunStats s = c->acc.finish(drop_last != 0, (uint32_t)c->p.ref_threads, group_offset, K, c->sc_host.data());
     memset(st, 0, sizeof *st);
@@ -417,6 +436,7 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
+    c->sc_host.clear(); c->sc_on_device = 0; c->bytes_unsynced = 0;
     c->res_used = c->res_folded = 0;
     c->h_len = 0;
     c->out_pairs.clear(); c->out_sam.clear(); c->tail_pairs.clear(); c->tail_sam.clear();
