@@ -26,7 +26,8 @@ struct mkt_ctx {
     uint8_t* d_in = nullptr;
     uint8_t* d_pairs = nullptr; size_t pairs_cap = 0;
     uint8_t* d_sam = nullptr; size_t sam_cap = 0;
-    uint64_t* d_sc = nullptr; size_t sc_cap = 0;
+    uint64_t* d_sc = nullptr; size_t sc_cap = 0;          // the run's resolved self-circle list (drained at syncs)
+    uint64_t* d_sc_tmp = nullptr; size_t sc_tmp_cap = 0;  // per block: raw (tile, ordinal) entries, one slice per region
     uint8_t* d_ws = nullptr; size_t ws_cap = 0;
     DevRun* d_run = nullptr;
     // host (pinned)
@@ -50,6 +51,7 @@ struct mkt_ctx {
     char* d_syn = nullptr; size_t syn_cap = 0;
     uint64_t* d_syn_sizes = nullptr; size_t syn_sizes_cap = 0;
     unsigned long long* d_stamps = nullptr;   // diagnostic builds (MKT_STAMPS) only
+    bool no_lean = false;                     // MKT_NO_LEAN=1: generic kernel only (debugging aid)
     std::string err;
 };
 
@@ -93,12 +95,14 @@ int mkt_device_count(void) {
     return n;
 }
 
-// workspace of one block: descA | descB | descC | tile_last | tile_groups | ticket (256 B) | BlockResult
+// workspace of one block: descA | descB | descC | tile_last | tile_groups | defer_list |
+//                         region cursors (16 x 128 B) | ticket, defer_count, ticket of the deferred pass (256 B) | BlockResult
 static size_t ws_tiles_bytes(uint32_t ntiles) {
-    size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + sizeof(uint32_t));
-    return (b + 15) & ~(size_t)15;
+    size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + 2 * sizeof(uint32_t));
+    return (b + 127) & ~(size_t)127;
 }
-static size_t ws_bytes_for(uint32_t ntiles) { return ws_tiles_bytes(ntiles) + 256 + sizeof(BlockResult); }
+static size_t ws_fixed_bytes() { return kMaxRegions * sizeof(RegionCur) + 256; }
+static size_t ws_bytes_for(uint32_t ntiles) { return ws_tiles_bytes(ntiles) + ws_fixed_bytes() + sizeof(BlockResult); }
 static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
     size_t need = ws_bytes_for(ntiles);
     if (need <= c->ws_cap) return MKT_OK;
@@ -130,6 +134,7 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
     c->p = *p;
     c->P.mode = p->mode; c->P.ratio = p->min_mapped_ratio; c->P.min_mapq = (uint32_t)p->min_mapq; c->P.write_sam = p->write_sam ? 1 : 0;
     c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;
+    { const char* e = getenv("MKT_NO_LEAN"); c->no_lean = e && e[0] == '1'; }
     size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)256 << 20);
     if (bc < 4096) bc = 4096;
     if (bc >= ((size_t)1 << 30)) bc = ((size_t)1 << 30) - 4096;
@@ -157,6 +162,7 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_pairs) hipFree(c->d_pairs);
     if (c->d_sam) hipFree(c->d_sam);
     if (c->d_sc) hipFree(c->d_sc);
+    if (c->d_sc_tmp) hipFree(c->d_sc_tmp);
     if (c->d_ws) hipFree(c->d_ws);
     if (c->d_run) hipFree(c->d_run);
     if (c->d_syn) hipFree(c->d_syn);
@@ -178,7 +184,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     // output capacities: .sam is at most the block (+1 for a missing final newline); .pairs is
     // checked in-kernel and grown on demand (the result carries the exact size)
     if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, n / 3 + 65536))) return rc;
-    if (c->P.write_sam && (rc = ensure_dev(c, &c->d_sam, &c->sam_cap, n + 64))) return rc;
+    if (c->P.write_sam && (rc = ensure_dev(c, &c->d_sam, &c->sam_cap, n + n / 4 + 65536))) return rc;
     if (!c->d_sc) {
         size_t need = (size_t)1 << 25;          // 32 Mi self-circle indices between two drains (256 MiB)
         HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
@@ -192,15 +198,35 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.descB = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.descC = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.tile_last = (TileLast*)w; w += (size_t)ntiles * sizeof(TileLast);
-    a.tile_groups = (uint32_t*)w;
+    a.tile_groups = (uint32_t*)w; w += (size_t)ntiles * sizeof(uint32_t);
+    a.defer_list = (uint32_t*)w;
     w = c->d_ws + ws_tiles_bytes(ntiles);
-    a.ticket = (uint32_t*)w; w += 256;
+    a.cur = (RegionCur*)w; w += kMaxRegions * sizeof(RegionCur);
+    a.ticket = (uint32_t*)w;
+    a.defer_count = (uint32_t*)(w + 64);
+    uint32_t* ticket2 = (uint32_t*)(w + 128);
+    w += 256;
     a.res = (BlockResult*)w;
     a.ordered = c->p.ordered ? 1 : 0;
     a.run = c->d_run;
+    // any-order mode: outputs in kMaxRegions equal slices (one cursor line each); ordered mode: one region
+    a.nregions = c->p.ordered ? 1 : kMaxRegions;
+    {
+        const size_t need = (size_t)a.nregions * ((n / 256 / (size_t)a.nregions) * 2 + 1024);
+        if (c->sc_tmp_cap < need) {
+            if (c->d_sc_tmp) HIPCHK(c, hipFree(c->d_sc_tmp));
+            c->d_sc_tmp = nullptr; c->sc_tmp_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_sc_tmp, need * sizeof(uint64_t)));
+            c->sc_tmp_cap = need;
+        }
+    }
+    a.pairs_rcap = (c->pairs_cap / a.nregions) & ~(uint64_t)15;
+    a.sam_rcap = c->P.write_sam ? ((c->sam_cap / a.nregions) & ~(uint64_t)15) : 0;
+    a.sc_rcap = c->sc_tmp_cap / a.nregions;
     a.out.pairs = c->d_pairs; a.out.pairs_cap = c->pairs_cap;
     a.out.sam = c->d_sam; a.out.sam_cap = c->P.write_sam ? c->sam_cap : 0;
-    a.out.sc = c->d_sc; a.out.sc_cap = c->sc_cap;
+    a.out.sc = c->d_sc_tmp; a.out.sc_cap = c->sc_tmp_cap;
+    a.sc_list = c->d_sc; a.sc_list_cap = c->sc_cap;
 #if defined(MKT_STAMPS)
     if (!c->d_stamps) { HIPCHK(c, hipMalloc((void**)&c->d_stamps, 16 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_stamps, 0, 16 * sizeof(unsigned long long))); }
     a.stamps = c->d_stamps;
@@ -211,9 +237,19 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     HIPCHK(c, hipEventCreate(&e1));
     c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
     int grid = (int)(ntiles < 1024u ? ntiles : 1024u);
+    const bool lean = !c->p.ordered && cfg == CFG_FAST && !c->no_lean;
     HIPCHK(c, hipEventRecord(e0, c->stream));
-    HIPCHK(c, launch_tiles(a, cfg, grid, c->stream));
-    HIPCHK(c, hipEventRecord(e1, c->stream));
+    if (lean) {
+        // lean kernel over all tiles, then the generic kernel over the tiles it deferred
+        HIPCHK(c, launch_fast(a, grid, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        KArgs b = a;
+        b.use_list = 1; b.ticket = ticket2;
+        HIPCHK(c, launch_tiles(b, cfg, ntiles < 256u ? (int)ntiles : 256, c->stream));
+    } else {
+        HIPCHK(c, launch_tiles(a, cfg, grid, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+    }
     HIPCHK(c, launch_finish(a, c->stream));
     HIPCHK(c, hipMemcpyAsync(&c->h_res[slot], a.res, sizeof(BlockResult), hipMemcpyDeviceToHost, c->stream));
     return MKT_OK;
@@ -266,14 +302,28 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         if (attempt >= 3) return check_result(c, r);
         if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg == CFG_FAST && c->p.tiles == MKT_TILES_AUTO) { cfg = CFG_SMALL; continue; }
         bool grew = false;
-        if (r.err & E_PAIRS_CAP) { if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, r.pair_bytes + 4096))) return rc; grew = true; }
-        if (r.err & E_SAM_CAP) { if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, r.sam_bytes + 4096))) return rc; grew = true; }
-        if (r.err & E_SC_CAP) {            // the list is drained after every host block: it only has to hold this block's
-            size_t need = (size_t)r.sc * 2 + 4096;
-            HIPCHK(c, hipFree(c->d_sc));
-            c->d_sc = nullptr; c->sc_cap = 0;
-            HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
-            c->sc_cap = need; grew = true;
+        const uint32_t nr = r.nregions ? r.nregions : 1;
+        if (r.err & E_PAIRS_CAP) {
+            uint64_t mx = 0; for (uint32_t q = 0; q < nr; ++q) if (r.rpair[q] > mx) mx = r.rpair[q];
+            if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc; grew = true;
+        }
+        if (r.err & E_SAM_CAP) {
+            uint64_t mx = 0; for (uint32_t q = 0; q < nr; ++q) if (r.rsam[q] > mx) mx = r.rsam[q];
+            if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc; grew = true;
+        }
+        if (r.err & E_SC_CAP) {            // per-block raw entries: grow the slices; the run's list is drained after every host block
+            size_t need = (size_t)r.sc * 4 + 65536;
+            if (c->d_sc_tmp) HIPCHK(c, hipFree(c->d_sc_tmp));
+            c->d_sc_tmp = nullptr; c->sc_tmp_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_sc_tmp, need * kMaxRegions * sizeof(uint64_t)));
+            c->sc_tmp_cap = need * kMaxRegions;
+            if (c->sc_cap < need) {
+                HIPCHK(c, hipFree(c->d_sc));
+                c->d_sc = nullptr; c->sc_cap = 0;
+                HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
+                c->sc_cap = need;
+            }
+            grew = true;
         }
         if (!grew) return check_result(c, r);
     }
@@ -284,8 +334,16 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     if ((rc = drain_sc(c))) return rc;
     size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
     if (c->h_stage.size() < pb + sb) c->h_stage.resize(pb + sb);
-    if (pb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data(), c->d_pairs, pb, hipMemcpyDeviceToHost, c->stream));
-    if (sb) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + pb, c->d_sam, sb, hipMemcpyDeviceToHost, c->stream));
+    // gather the region slices: .pairs regions first, then .sam regions; remember where each region landed
+    const uint32_t nreg = r.nregions ? r.nregions : 1;
+    const size_t prc = (c->pairs_cap / nreg) & ~(size_t)15, src_ = c->P.write_sam ? ((c->sam_cap / nreg) & ~(size_t)15) : 0;
+    size_t pstart[kMaxRegions], sstart[kMaxRegions], acc_p = 0, acc_s = pb;
+    for (uint32_t q = 0; q < nreg; ++q) {
+        pstart[q] = acc_p; sstart[q] = acc_s;
+        if (r.rpair[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + acc_p, c->d_pairs + (size_t)q * prc, (size_t)r.rpair[q], hipMemcpyDeviceToHost, c->stream));
+        if (sb && r.rsam[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + acc_s, c->d_sam + (size_t)q * src_, (size_t)r.rsam[q], hipMemcpyDeviceToHost, c->stream));
+        acc_p += (size_t)r.rpair[q]; acc_s += sb ? (size_t)r.rsam[q] : 0;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     const char* hp = (const char*)c->h_stage.data();
     if (r.last.valid) {
@@ -293,8 +351,9 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         // (its bytes sit at [pair_off, +pair_bytes) / [sam_off, +sam_bytes) of this block's outputs)
         c->out_pairs.insert(c->out_pairs.end(), c->tail_pairs.begin(), c->tail_pairs.end());
         c->out_sam.insert(c->out_sam.end(), c->tail_sam.begin(), c->tail_sam.end());
-        const size_t tp = r.last.pair_bytes, po = r.last.pair_off;
-        const size_t ts = c->P.write_sam ? r.last.sam_bytes : 0, so = r.last.sam_off;
+        const uint32_t lr = r.last.region < nreg ? r.last.region : 0;
+        const size_t tp = r.last.pair_bytes, po = pstart[lr] + r.last.pair_off;
+        const size_t ts = c->P.write_sam ? r.last.sam_bytes : 0, so = sb ? (sstart[lr] - pb) + r.last.sam_off : 0;
         c->out_pairs.insert(c->out_pairs.end(), hp, hp + po);
         c->out_pairs.insert(c->out_pairs.end(), hp + po + tp, hp + pb);
         c->tail_pairs.assign(hp + po, hp + po + tp);
@@ -388,17 +447,21 @@ int mkt_fetch_last_block(mkt_ctx* c, char* pairs, size_t pairs_cap, size_t* pair
     // the last folded result is not kept per block; re-read it from the device workspace
     BlockResult r;
     const uint32_t ntiles = num_tiles((uint32_t)c->last_n, tile_bytes(c->cfg));
-    const uint8_t* w = c->d_ws + ws_tiles_bytes(ntiles) + 256;
+    const uint8_t* w = c->d_ws + ws_tiles_bytes(ntiles) + ws_fixed_bytes();
     HIPCHK(c, hipMemcpy(&r, w, sizeof r, hipMemcpyDeviceToHost));
     if (pairs_len) *pairs_len = (size_t)r.pair_bytes;
     if (sam_len) *sam_len = c->P.write_sam ? (size_t)r.sam_bytes : 0;
+    const uint32_t nreg = r.nregions ? r.nregions : 1;
+    const size_t prc = (c->pairs_cap / nreg) & ~(size_t)15, src_ = c->P.write_sam ? ((c->sam_cap / nreg) & ~(size_t)15) : 0;
     if (pairs && r.pair_bytes) {
         if (pairs_cap < r.pair_bytes) return fail(c, MKT_E_ARG, "pairs buffer too small (%llu needed)", (unsigned long long)r.pair_bytes);
-        HIPCHK(c, hipMemcpy(pairs, c->d_pairs, (size_t)r.pair_bytes, hipMemcpyDeviceToHost));
+        size_t acc = 0;
+        for (uint32_t q = 0; q < nreg; ++q) { if (r.rpair[q]) HIPCHK(c, hipMemcpy(pairs + acc, c->d_pairs + (size_t)q * prc, (size_t)r.rpair[q], hipMemcpyDeviceToHost)); acc += (size_t)r.rpair[q]; }
     }
     if (sam && c->P.write_sam && r.sam_bytes) {
         if (sam_cap < r.sam_bytes) return fail(c, MKT_E_ARG, "sam buffer too small (%llu needed)", (unsigned long long)r.sam_bytes);
-        HIPCHK(c, hipMemcpy(sam, c->d_sam, (size_t)r.sam_bytes, hipMemcpyDeviceToHost));
+        size_t acc = 0;
+        for (uint32_t q = 0; q < nreg; ++q) { if (r.rsam[q]) HIPCHK(c, hipMemcpy(sam + acc, c->d_sam + (size_t)q * src_, (size_t)r.rsam[q], hipMemcpyDeviceToHost)); acc += (size_t)r.rsam[q]; }
     }
     return MKT_OK;
 }

@@ -263,10 +263,12 @@ MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, 
 
 MKT_HD uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 
-// bytewise std::string::compare of two byte ranges of the block
+// bytewise std::string::compare of two byte ranges of the block.  WIN: the caller guarantees that
+// both ranges lie inside the window (the lean kernel), so no global-memory path is generated.
+template <bool WIN = false>
 MKT_HD int text_cmp(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
     const uint32_t m = alen < blen ? alen : blen;
-    if (tv.inside(a, alen) && tv.inside(b, blen)) {
+    if (WIN || (tv.inside(a, alen) && tv.inside(b, blen))) {
         const uint32_t ra = a - tv.w0, rb = b - tv.w0;
         for (uint32_t i = 0; i < m; i += 4u) {
             uint32_t x = win_load4(tv, ra + i), y = win_load4(tv, rb + i);
@@ -281,9 +283,10 @@ MKT_HD int text_cmp(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, u
     }
     return alen < blen ? -1 : (alen > blen ? 1 : 0);
 }
+template <bool WIN = false>
 MKT_HD bool text_eq(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
     if (alen != blen) return false;
-    if (tv.inside(a, alen) && tv.inside(b, blen)) {
+    if (WIN || (tv.inside(a, alen) && tv.inside(b, blen))) {
         const uint32_t ra = a - tv.w0, rb = b - tv.w0;
         for (uint32_t i = 0; i < alen; i += 4u) {
             uint32_t x = win_load4(tv, ra + i) ^ win_load4(tv, rb + i);
@@ -351,10 +354,11 @@ MKT_HD Verdict verdict_none(uint32_t counter) {
 MKT_HD uint8_t strand_of(uint32_t flag) { return (flag & 16u) ? '-' : '+'; }
 
 // flash2pairs.h:110-144 / unc2pairs.h:315-348
+template <bool WIN = false>
 MKT_HD Verdict order_and_bin(const TextView& tv, uint32_t c1o, uint32_t c1l, uint32_t pos1, uint8_t s1,
                              uint32_t c2o, uint32_t c2l, uint32_t pos2, uint8_t s2) {
     Verdict v;
-    int chrcmp = text_cmp(tv, c1o, c1l, c2o, c2l);
+    int chrcmp = text_cmp<WIN>(tv, c1o, c1l, c2o, c2l);
     if (chrcmp < 0 || (chrcmp == 0 && pos1 < pos2)) {
         v.chrA_off = c1o; v.chrA_len = c1l; v.posA = pos1; v.sA = s1;
         v.chrB_off = c2o; v.chrB_len = c2l; v.posB = pos2; v.sB = s2;
@@ -374,6 +378,7 @@ MKT_HD Verdict order_and_bin(const TextView& tv, uint32_t c1o, uint32_t c1l, uin
 }
 
 // flash2pairs.h:17-155.  n = surviving records in the group, a/b = the first two.
+template <bool WIN = false>
 MKT_HD Verdict classify_flash(const TextView& tv, uint32_t n, const Seg& a, const Seg& b, float ratio) {
     if (n == 1) {
         if (a.segCnt > 2) return verdict_none(C_MANYHITS);
@@ -394,17 +399,19 @@ MKT_HD Verdict classify_flash(const TextView& tv, uint32_t n, const Seg& a, cons
         uint32_t pos1 = a.pos, pos2 = b.pos;
         if (a.lclip > a.rclip) pos1 = (uint32_t)a.right0;
         if (b.lclip > b.rclip) pos2 = (uint32_t)b.right0;
-        return order_and_bin(tv, a.chr_off, a.chr_len, pos1, strand_of(a.flag), b.chr_off, b.chr_len, pos2, strand_of(b.flag));
+        return order_and_bin<WIN>(tv, a.chr_off, a.chr_len, pos1, strand_of(a.flag), b.chr_off, b.chr_len, pos2, strand_of(b.flag));
     }
     return verdict_none(C_MANYHITS);
 }
 
+template <bool WIN = false>
 MKT_HD bool pairable(const TextView& tv, const Seg& x, const Seg& y, int32_t lo_left, int32_t hi_left, int32_t hi_right) {
-    return text_cmp(tv, x.chr_off, x.chr_len, y.chr_off, y.chr_len) == 0 && lo_left < hi_left && hi_right - lo_left <= kMaxPairDist;
+    return text_cmp<WIN>(tv, x.chr_off, x.chr_len, y.chr_off, y.chr_len) == 0 && lo_left < hi_left && hi_right - lo_left <= kMaxPairDist;
 }
 MKT_HD uint32_t clip_side_pos(const Seg& s) { return (uint32_t)(s.lclip > s.rclip ? s.right0 : s.left0); }
 
 // unc2pairs.h:16-358.  n1/n2 = records with FLAG&64 / (else) FLAG&128; r1a,r1b / r2a,r2b = the first two of each.
+template <bool WIN = false>
 MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const Seg& r1a, const Seg& r1b,
                             const Seg& r2a, const Seg& r2b, float ratio) {
     if (n1 == 0 || n2 == 0) return verdict_none(C_NONE);        // :52-55
@@ -412,7 +419,7 @@ MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const 
     uint32_t c1o, c1l, c2o, c2l, pos1 = 0, pos2 = 0;
     uint8_t st1, st2;
     if (n1 == 1 && n2 == 1) {                                   // category 0
-        const Seg& s1 = r1a; const Seg& s2 = r2a;
+        const Seg& s1 = r1a; const Seg& s2 = r2a;      // fixed aliases (no run-time choice)
         if (!integrity_1(s1, ratio)) return verdict_none(C_LOWMAP);
         if (!integrity_1(s2, ratio)) return verdict_none(C_LOWMAP);
         if (s1.segCnt + s2.segCnt > 3) return verdict_none(C_MANYHITS);
@@ -423,27 +430,28 @@ MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const 
             pos2 = (uint32_t)(st2 == '+' ? s2.left0 : s2.right0);
         } else if (s1.segCnt == 2) {
             if (st1 == '+') {
-                if (st2 == '-' && pairable(tv, s1, s2, s1.left1, s2.left0, s2.right0)) { pos1 = (uint32_t)s1.left0; pos2 = (uint32_t)s2.right0; }
+                if (st2 == '-' && pairable<WIN>(tv, s1, s2, s1.left1, s2.left0, s2.right0)) { pos1 = (uint32_t)s1.left0; pos2 = (uint32_t)s2.right0; }
                 else return verdict_none(C_UNPAIRED);
             } else {
-                if (st2 == '+' && pairable(tv, s1, s2, s2.left0, s1.left0, s1.right0)) { pos1 = (uint32_t)s1.right1; pos2 = (uint32_t)s2.left0; }
+                if (st2 == '+' && pairable<WIN>(tv, s1, s2, s2.left0, s1.left0, s1.right0)) { pos1 = (uint32_t)s1.right1; pos2 = (uint32_t)s2.left0; }
                 else return verdict_none(C_UNPAIRED);
             }
         } else {
             if (st1 == '+') {
-                if (st2 == '-' && pairable(tv, s1, s2, s1.left0, s2.left0, s2.right0)) { pos1 = (uint32_t)s1.left0; pos2 = (uint32_t)s2.right1; }
+                if (st2 == '-' && pairable<WIN>(tv, s1, s2, s1.left0, s2.left0, s2.right0)) { pos1 = (uint32_t)s1.left0; pos2 = (uint32_t)s2.right1; }
                 else return verdict_none(C_UNPAIRED);
             } else {
-                if (st2 == '+' && pairable(tv, s1, s2, s2.left1, s1.left0, s1.right0)) { pos1 = (uint32_t)s1.right0; pos2 = (uint32_t)s2.left0; }
+                if (st2 == '+' && pairable<WIN>(tv, s1, s2, s2.left1, s1.left0, s1.right0)) { pos1 = (uint32_t)s1.right0; pos2 = (uint32_t)s2.left0; }
                 else return verdict_none(C_UNPAIRED);
             }
         }
     } else {
-        // categories 1 (1+2) and 2 (2+1): `u` is the read with one record, v0/v1 the split read
+        // categories 1 (1+2) and 2 (2+1): `u` is the read with one record, v0/v1 the split read.
+        // (copies, not references picked at run time: those would force the records into scratch memory)
         const bool cat1 = (n1 == 1);
-        const Seg& u = cat1 ? r1a : r2a;
-        const Seg& v0 = cat1 ? r2a : r1a;
-        const Seg& v1 = cat1 ? r2b : r1b;
+        const Seg u = cat1 ? r1a : r2a;
+        const Seg v0 = cat1 ? r2a : r1a;
+        const Seg v1 = cat1 ? r2b : r1b;
         if (cat1) {                                             // :62-98
             if (!integrity_1(u, ratio)) return verdict_none(C_LOWMAP);
             if (!integrity_2(v0, v1, ratio)) return verdict_none(C_LOWMAP);
@@ -453,23 +461,25 @@ MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const 
         }
         if (u.segCnt != 1 || v0.segCnt != 1 || v1.segCnt != 1) return verdict_none(C_MANYHITS);
         const uint8_t su = strand_of(u.flag);
-        uint32_t posu = 0;
-        int mate = -1;
-        for (int k = 0; k < 2 && mate < 0; ++k) {               // :196-227 / :255-285
-            const Seg& w = k == 0 ? v0 : v1;
-            if (su == '+') {
-                if (strand_of(w.flag) == '-' && pairable(tv, u, w, u.left0, w.left0, w.right0)) { posu = (uint32_t)u.left0; mate = k; }
-            } else {
-                if (strand_of(w.flag) == '+' && pairable(tv, u, w, w.left0, u.left0, u.right0)) { posu = (uint32_t)u.right0; mate = k; }
-            }
+        const uint32_t posu = (uint32_t)(su == '+' ? u.left0 : u.right0);
+        // try v0 then v1 (:196-227 / :255-285)
+        bool m0, m1;
+        if (su == '+') {
+            m0 = strand_of(v0.flag) == '-' && pairable<WIN>(tv, u, v0, u.left0, v0.left0, v0.right0);
+            m1 = strand_of(v1.flag) == '-' && pairable<WIN>(tv, u, v1, u.left0, v1.left0, v1.right0);
+        } else {
+            m0 = strand_of(v0.flag) == '+' && pairable<WIN>(tv, u, v0, v0.left0, u.left0, u.right0);
+            m1 = strand_of(v1.flag) == '+' && pairable<WIN>(tv, u, v1, v1.left0, u.left0, u.right0);
         }
-        if (mate < 0) return verdict_none(C_UNPAIRED);          // :229-232 / :287-290
-        const Seg& o = mate == 0 ? v1 : v0;                     // the OTHER record of the split read
-        const uint32_t poso = clip_side_pos(o);
-        if (cat1) { c1o = u.chr_off; c1l = u.chr_len; pos1 = posu; st1 = su; c2o = o.chr_off; c2l = o.chr_len; pos2 = poso; st2 = strand_of(o.flag); }
-        else      { c2o = u.chr_off; c2l = u.chr_len; pos2 = posu; st2 = su; c1o = o.chr_off; c1l = o.chr_len; pos1 = poso; st1 = strand_of(o.flag); }
+        if (!m0 && !m1) return verdict_none(C_UNPAIRED);        // :229-232 / :287-290
+        // the OTHER record of the split read gives the second end
+        const uint32_t oo = m0 ? v1.chr_off : v0.chr_off, ol = m0 ? v1.chr_len : v0.chr_len;
+        const uint32_t poso = m0 ? clip_side_pos(v1) : clip_side_pos(v0);
+        const uint8_t so = strand_of(m0 ? v1.flag : v0.flag);
+        if (cat1) { c1o = u.chr_off; c1l = u.chr_len; pos1 = posu; st1 = su; c2o = oo; c2l = ol; pos2 = poso; st2 = so; }
+        else      { c2o = u.chr_off; c2l = u.chr_len; pos2 = posu; st2 = su; c1o = oo; c1l = ol; pos1 = poso; st1 = so; }
     }
-    return order_and_bin(tv, c1o, c1l, pos1, st1, c2o, c2l, pos2, st2);
+    return order_and_bin<WIN>(tv, c1o, c1l, pos1, st1, c2o, c2l, pos2, st2);
 }
 
 MKT_HD uint32_t dec_digits(uint32_t v) {
@@ -495,12 +505,13 @@ MKT_HD uint32_t dec_digit(uint32_t v, uint32_t from_right) {      // digit 10^fr
     }
 }
 // byte k of  rid \t chrA \t posA \t chrB \t posB \t sA \t sB \n   (flash2pairs.h:123-127)
+template <bool WIN = false>
 MKT_HD uint8_t pair_line_byte(const TextView& tv, uint32_t qn_abs, uint32_t qn_len, const Verdict& v, uint32_t k) {
-    if (k < qn_len) return tv.at(qn_abs + k);
+    if (k < qn_len) return WIN ? tv.win[qn_abs + k - tv.w0] : tv.at(qn_abs + k);
     k -= qn_len;
     if (k == 0) return '\t';
     k -= 1;
-    if (k < v.chrA_len) return tv.at(v.chrA_off + k);
+    if (k < v.chrA_len) return WIN ? tv.win[v.chrA_off + k - tv.w0] : tv.at(v.chrA_off + k);
     k -= v.chrA_len;
     if (k == 0) return '\t';
     k -= 1;
@@ -509,7 +520,7 @@ MKT_HD uint8_t pair_line_byte(const TextView& tv, uint32_t qn_abs, uint32_t qn_l
     k -= dA;
     if (k == 0) return '\t';
     k -= 1;
-    if (k < v.chrB_len) return tv.at(v.chrB_off + k);
+    if (k < v.chrB_len) return WIN ? tv.win[v.chrB_off + k - tv.w0] : tv.at(v.chrB_off + k);
     k -= v.chrB_len;
     if (k == 0) return '\t';
     k -= 1;

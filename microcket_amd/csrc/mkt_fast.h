@@ -1,0 +1,253 @@
+// mkt_fast.h -- the lean tile path of the fused sam2pairs kernel (k_fast in mkt_kernels.hip).
+//
+// Same algorithm as mkt_tile.h, restricted to what well-formed name-grouped SAM looks like so that
+// the hot kernel carries no generic code: every line's six fields end inside its first 128 bytes
+// and inside the window, every group opened in the tile closes inside the window, and the previous
+// surviving line sits in the back halo.  A tile that violates any of this sets `abn` and is left
+// untouched: the host runs the generic kernel (k_tiles, mkt_tile.h) over the list of such tiles.
+// Outputs go to atomically allocated ranges, so the two kernels compose freely.
+//
+// State is packed (16-bit window-relative offsets, 8-bit field lengths) to keep one tile at about
+// 36 KB of LDS: four workgroups per CU.  The phase functions are host+device so that
+// tests/host/tile_emul.cpp checks this logic on the CPU as well.
+#pragma once
+#include "mkt_tile.h"
+
+namespace mkt {
+
+template <int TILE_, int HB_, int HF_, int LCAP_>
+struct FastCfg {
+    static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
+    static constexpr int MW = (W + 63) / 64 + 3;
+    static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
+    static_assert(W < 65536, "window-relative offsets are 16 bit");
+    static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
+};
+
+constexpr uint8_t LB_EMIT = 8;          // line belongs to an emitting group (its bytes go to the .sam)
+
+template <class Cfg>
+struct FastState {
+    alignas(16) uint8_t win[Cfg::W + 16];
+    // per line of the window
+    uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP];
+    uint32_t right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP];
+    uint16_t off16[Cfg::LCAP];           // line start, window relative
+    uint16_t flag[Cfg::LCAP];
+    uint8_t qn_off[Cfg::LCAP], qn_len[Cfg::LCAP], rn_off[Cfg::LCAP], rn_len[Cfg::LCAP], segCnt[Cfg::LCAP], bits[Cfg::LCAP];
+    union alignas(16) Phase {
+        struct { uint64_t nlm[Cfg::MW], wsm[Cfg::MW]; } m;     // while parsing
+        struct {                                               // afterwards, indexed by the group's first line / by line
+            uint32_t g_info[Cfg::LCAP], g_posA[Cfg::LCAP], g_posB[Cfg::LCAP], g_slen[Cfg::LCAP];
+            uint32_t x_sam[Cfg::LCAP];                         // per LINE: offset of its bytes in the tile's .sam output
+            uint16_t g_chrA[Cfg::LCAP], g_chrB[Cfg::LCAP];     // window-relative RNAME offsets
+            uint16_t g_plen[Cfg::LCAP], x_pair[Cfg::LCAP];
+            uint8_t g_chrA_len[Cfg::LCAP], g_chrB_len[Cfg::LCAP];
+            uint8_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP], em_idx[Cfg::LCAP];
+        } g;
+    } u;
+    uint32_t NL, first_idx, end_idx, abn, last_line_end;
+    uint32_t cnt[C_COUNT];
+    TileSums sums, base;                  // base: ABSOLUTE positions in OutPtrs::pairs / sam / sc
+    uint32_t region_pair0, region_sam0, region_id;
+};
+
+template <class Cfg> MKT_HD TileGeom fast_geom(uint32_t tile, uint32_t n) {
+    TileGeom G;
+    uint64_t t0 = (uint64_t)tile * Cfg::TILE, t1 = t0 + Cfg::TILE;
+    G.t0 = (uint32_t)t0;
+    G.t1 = t1 < n ? (uint32_t)t1 : n;
+    G.w0 = G.t0 >= (uint32_t)Cfg::HB ? G.t0 - Cfg::HB : 0u;
+    uint64_t w1 = (uint64_t)G.t1 + Cfg::HF;
+    G.w1 = w1 < n ? (uint32_t)w1 : n;
+    return G;
+}
+template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G) {
+    TextView tv;
+    tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = G.w1 - G.w0; tv.nlm = st.u.m.nlm; tv.wsm = st.u.m.wsm;
+    return tv;
+}
+template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
+    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown;
+    st.region_pair0 = 0; st.region_sam0 = 0; st.region_id = 0;
+    for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
+}
+// lines that take part: a trailing window-cut halo line does not
+template <class Cfg> MKT_HD uint32_t fast_nle(const FastState<Cfg>& st) {
+    return (st.NL && (st.bits[st.NL - 1] & LB_CUT)) ? st.NL - 1u : st.NL;
+}
+template <class Cfg> MKT_HD uint32_t fast_line_end(const FastState<Cfg>& st, const TileGeom& G, uint32_t i) {
+    return i + 1 < st.NL ? G.w0 + st.off16[i + 1] - 1u : st.last_line_end;
+}
+
+// ---- parse line i ------------------------------------------------------------------------------
+template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
+    const uint32_t off = G.w0 + st.off16[i];
+    if (i + 1 == st.NL) {
+        uint32_t e;
+        if (G.w1 - 1 >= off && tv.win[G.w1 - 1 - G.w0] == '\n') e = G.w1 - 1;
+        else e = G.w1 >= tv.n ? tv.n : kUnknown;
+        st.last_line_end = e;
+    }
+    if (off >= G.t0 && (i == 0 || G.w0 + st.off16[i - 1] < G.t0)) st.first_idx = i;
+    if (off >= G.t1 && (i == 0 || G.w0 + st.off16[i - 1] < G.t1)) st.end_idx = i;
+    Rec r;
+    const int pf = parse_record_fast(tv, off, P, r);
+    if (pf != PF_OK) {
+        if (pf == PF_CUT && off >= G.t1) st.bits[i] = LB_CUT;      // last halo line, cut by the window: ignored
+        else { st.bits[i] = 0; st.abn = 1; }                       // fields beyond 128 bytes: generic kernel
+        return;
+    }
+    st.pos[i] = r.pos; st.lclip[i] = (uint32_t)r.lclip; st.rclip[i] = (uint32_t)r.rclip; st.mappable[i] = (uint32_t)r.mappable;
+    st.right0[i] = (uint32_t)r.right0; st.left1[i] = (uint32_t)r.left1; st.right1[i] = (uint32_t)r.right1;
+    st.flag[i] = (uint16_t)(r.flag & 0xFFFFu);
+    st.qn_off[i] = (uint8_t)r.qn_off; st.qn_len[i] = (uint8_t)r.qn_len; st.rn_off[i] = (uint8_t)r.rn_off; st.rn_len[i] = (uint8_t)r.rn_len;
+    st.segCnt[i] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
+    uint8_t b = r.survive ? LB_SURVIVE : 0;
+    if (i > 0) {
+        // same QNAME token as the line before: its first token must start at its first byte
+        const uint32_t poff = G.w0 + st.off16[i - 1];
+        const uint32_t ql = r.qn_len;
+        if (is_ws(tv.win[poff - G.w0])) st.abn = 1;
+        else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql - G.w0])) b |= LB_EQPREV;
+    }
+    st.bits[i] = b;
+}
+
+// ---- does surviving line i open a group? ---------------------------------------------------------
+template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextView& tv, const TileGeom& G, uint32_t i) {
+    bool chain = true;
+    uint32_t j = i;
+    for (;;) {
+        if (j == 0) {
+            if (G.w0 == 0) return true;               // first surviving line of the block
+            st.abn = 1;                               // the previous surviving line is before the window
+            return false;
+        }
+        chain = chain && (st.bits[j] & LB_EQPREV);
+        --j;
+        if (st.bits[j] & LB_SURVIVE) break;
+    }
+    if (chain) return false;
+    return !text_eq<true>(tv, G.w0 + st.off16[i] + st.qn_off[i], st.qn_len[i], G.w0 + st.off16[j] + st.qn_off[j], st.qn_len[j]);
+}
+
+template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, const TileGeom& G, uint32_t idx) {
+    Seg s;
+    s.segCnt = st.segCnt[idx]; s.lclip = (int32_t)st.lclip[idx]; s.rclip = (int32_t)st.rclip[idx]; s.mappable = (int32_t)st.mappable[idx];
+    s.left0 = (int32_t)st.pos[idx]; s.left1 = (int32_t)st.left1[idx]; s.right0 = (int32_t)st.right0[idx]; s.right1 = (int32_t)st.right1[idx];
+    s.rightLast = s.segCnt == 2 ? s.right1 : s.right0;
+    s.flag = st.flag[idx]; s.pos = st.pos[idx];
+    s.chr_off = G.w0 + st.off16[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];
+    return s;
+}
+
+// ---- walk + classify the group opened by line i --------------------------------------------------
+template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
+    auto& g = st.u.g;
+    g.g_info[i] = 0; g.g_plen[i] = 0; g.g_slen[i] = 0;
+    if (!(st.bits[i] & LB_SURVIVE) || !fast_is_start(st, tv, G, i)) return;
+    const uint32_t NLe = fast_nle(st);
+    uint32_t nmem = 0, n1 = 0, n2 = 0, sa = 0xFFFFu, sb = 0xFFFFu, sc = 0xFFFFu, sd = 0xFFFFu, sam_bytes = 0;
+    uint32_t j = i;
+    bool closed = false;
+    while (j < NLe) {
+        const uint8_t b = st.bits[j];
+        if (b & LB_SURVIVE) {
+            if (j > i) {
+                bool same;
+                if ((b & LB_EQPREV) && (st.bits[j - 1] & LB_SURVIVE)) same = true;
+                else same = !fast_is_start(st, tv, G, j);
+                if (!same) { closed = true; break; }
+            }
+            const uint32_t f = st.flag[j];
+            if (P.mode == MODE_FLASH) { if (nmem == 0) sa = j; else if (nmem == 1) sb = j; }
+            else if (f & 64u) { if (n1 == 0) sa = j; else if (n1 == 1) sb = j; ++n1; }
+            else if (f & 128u) { if (n2 == 0) sc = j; else if (n2 == 1) sd = j; ++n2; }
+            ++nmem;
+            const uint32_t e = fast_line_end(st, G, j);
+            if (e == kUnknown || e >= tv.n) st.abn = 1;           // line end beyond the window / no final newline
+            else sam_bytes += e + 1u - (G.w0 + st.off16[j]);
+        }
+        ++j;
+    }
+    if (!closed && G.w1 < tv.n) { st.abn = 1; return; }           // the group may continue past the window
+    Verdict v;
+    {
+        Seg a = sa != 0xFFFFu ? fast_seg(st, G, sa) : seg_zero();
+        Seg b = sb != 0xFFFFu ? fast_seg(st, G, sb) : seg_zero();
+        if (P.mode == MODE_FLASH) v = classify_flash<true>(tv, nmem, a, b, P.ratio);
+        else {
+            Seg c = sc != 0xFFFFu ? fast_seg(st, G, sc) : seg_zero();
+            Seg d = sd != 0xFFFFu ? fast_seg(st, G, sd) : seg_zero();
+            v = classify_unc<true>(tv, n1, n2, a, b, c, d, P.ratio);
+        }
+    }
+    uint32_t info = GI_START | (v.counter & GI_COUNTER);
+    if (v.emit) {
+        info |= GI_EMIT;
+        if (v.sA == '-') info |= GI_SA_MINUS;
+        if (v.sB == '-') info |= GI_SB_MINUS;
+        g.g_posA[i] = v.posA; g.g_posB[i] = v.posB;
+        g.g_chrA[i] = (uint16_t)(v.chrA_off - G.w0); g.g_chrB[i] = (uint16_t)(v.chrB_off - G.w0);
+        g.g_chrA_len[i] = (uint8_t)v.chrA_len; g.g_chrB_len[i] = (uint8_t)v.chrB_len;
+        g.g_plen[i] = (uint16_t)pair_line_len(st.qn_len[i], v);
+        if (P.write_sam) {
+            g.g_slen[i] = sam_bytes;
+            for (uint32_t k = i; k < j; ++k) if (st.bits[k] & LB_SURVIVE) st.bits[k] |= LB_EMIT;    // members (byte-wide RMW, other bits untouched)
+        }
+    }
+    g.g_info[i] = info;
+}
+
+// bytes line i contributes to the tile's .sam output
+template <class Cfg> MKT_HD uint32_t fast_line_sam(const FastState<Cfg>& st, const TileGeom& G, uint32_t i) {
+    if (!(st.bits[i] & LB_EMIT)) return 0u;
+    return fast_line_end(st, G, i) + 1u - (G.w0 + st.off16[i]);
+}
+
+// ---- account for the group opened by line i (counters, self-circle entry) ------------------------
+template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs& out, uint32_t tile, uint32_t i) {
+    const uint32_t info = st.u.g.g_info[i];
+    if (!(info & GI_START)) return;
+    const uint32_t counter = info & GI_COUNTER;
+    if (counter) lds_add(&st.cnt[counter], 1u);
+    if (counter == C_SELFCIRCLE) {
+        uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
+        if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
+        else st.abn = E_SC_CAP << 8;                  // reported as an error bit by the kernel
+    }
+}
+template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, TileLast* tl, uint32_t i) {
+    const auto& g = st.u.g;
+    const uint32_t info = g.g_info[i];
+    if (!(info & GI_START)) return;
+    if ((uint32_t)g.x_grp[i] + 1u != st.sums.groups) return;
+    tl->counter = info & GI_COUNTER;
+    tl->pair_bytes = g.g_plen[i];
+    tl->sam_bytes = g.g_slen[i];
+    tl->pair_off = st.base.pair_bytes - st.region_pair0 + g.x_pair[i];
+    tl->sam_off = (uint32_t)(st.base.sam_bytes - st.region_sam0 + g.x_sam[i]);
+    tl->region = st.region_id; tl->pad = 0;
+    tl->valid = 1;
+}
+
+// byte k (0 <= k < sums.pair_bytes) of the tile's .pairs output
+template <class Cfg> MKT_HD uint8_t fast_pair_byte(const FastState<Cfg>& st, const TextView& tv, const TileGeom& G, uint32_t k) {
+    const auto& g = st.u.g;
+    uint32_t lo = 0, hi = st.sums.emitted;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (g.x_pair[g.em_idx[mid]] <= k) lo = mid; else hi = mid;
+    }
+    const uint32_t i = g.em_idx[lo];
+    const uint32_t info = g.g_info[i];
+    Verdict v;
+    v.counter = info & GI_COUNTER; v.emit = true;
+    v.chrA_off = G.w0 + g.g_chrA[i]; v.chrA_len = g.g_chrA_len[i]; v.chrB_off = G.w0 + g.g_chrB[i]; v.chrB_len = g.g_chrB_len[i];
+    v.posA = g.g_posA[i]; v.posB = g.g_posB[i];
+    v.sA = (info & GI_SA_MINUS) ? '-' : '+'; v.sB = (info & GI_SB_MINUS) ? '-' : '+';
+    return pair_line_byte<true>(tv, G.w0 + st.off16[i] + st.qn_off[i], st.qn_len[i], v, k - g.x_pair[i]);
+}
+
+}  // namespace mkt

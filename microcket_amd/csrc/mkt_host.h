@@ -23,6 +23,8 @@ struct BlockResult {            // written by the device (finish kernel), POD
     uint32_t err;
     TileLast last;              // last group of the block (valid = 0: the block holds no group)
     uint32_t tiles, pad;
+    uint32_t nregions, pad2;    // outputs sit in nregions equal slices of the output buffers (any-order mode: 16)
+    uint64_t rpair[16], rsam[16];   // bytes used in each slice
 };
 
 struct RunStats {               // what the .log needs, plus bookkeeping
@@ -37,7 +39,7 @@ struct RunAccum {
     uint64_t groups = 0, emitted = 0, pair_bytes = 0, sam_bytes = 0;
     uint64_t counters[C_COUNT] = {0};
     uint64_t sc = 0;                   // self-circle groups so far (their indices live in the sc list)
-    TileLast pending = {0, 0, 0, 0, 0, 0};   // newest group (held back: it may be the input's last, quirk Q1)
+    TileLast pending = {0, 0, 0, 0, 0, 0, 0, 0};   // newest group (held back: it may be the input's last, quirk Q1)
 
     void add_block(const BlockResult& r) {
         sc += r.sc;

@@ -110,6 +110,29 @@ __device__ inline uint64_t lookback(uint64_t* desc, uint32_t t, uint64_t agg, ui
     return excl;
 }
 
+// Any-order mode: the tile claims its output ranges from the cursors of its region with one 64-bit
+// atomic (.pairs bytes + emitted lines) and, only when needed, a second one (.sam bytes + self-circles).
+// Executed by ONE thread.  Returns error bits.
+__device__ inline uint32_t claim_ranges(const KArgs& a, uint32_t region, const TileSums& sums, TileSums& base,
+                                        uint32_t& region_pair0, uint32_t& region_sam0, OutPtrs& lim) {
+    RegionCur* cur = a.cur + region;
+    uint32_t err = 0;
+    const uint64_t p0 = (uint64_t)region * a.pairs_rcap, s0 = (uint64_t)region * a.sam_rcap, c0 = (uint64_t)region * a.sc_rcap;
+    unsigned long long oa = 0, ob = 0;
+    if (sums.pair_bytes | sums.emitted) oa = atomicAdd(&cur->a, (unsigned long long)sums.pair_bytes | ((unsigned long long)sums.emitted << 40));
+    if (sums.sam_bytes | sums.sc) ob = atomicAdd(&cur->b, (unsigned long long)sums.sam_bytes | ((unsigned long long)sums.sc << 40));
+    const uint64_t op = oa & kLow40, os = ob & kLow40, oc = ob >> 40;
+    if (op + sums.pair_bytes > a.pairs_rcap) err |= E_PAIRS_CAP;
+    if (os + sums.sam_bytes > a.sam_rcap) err |= E_SAM_CAP;
+    if (oc + sums.sc > a.sc_rcap) err |= E_SC_CAP;
+    base.pair_bytes = (uint32_t)(p0 + op); base.sam_bytes = s0 + os; base.sc = (uint32_t)(c0 + oc);
+    region_pair0 = (uint32_t)p0; region_sam0 = (uint32_t)s0;
+    lim.pairs_cap = err & E_PAIRS_CAP ? 0 : p0 + a.pairs_rcap;     // an overflowing tile writes nothing
+    lim.sam_cap = err & E_SAM_CAP ? 0 : s0 + a.sam_rcap;
+    lim.sc_cap = err & E_SC_CAP ? 0 : c0 + a.sc_rcap;
+    return err;
+}
+
 template <class Cfg>
 __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
     __shared__ TileState<Cfg> st;
@@ -122,8 +145,8 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
     const int tid = threadIdx.x;
     const Params P = a.P;
     const uint32_t n = a.n;
-    OutPtrs out = a.out;
-    out.sc_base = a.run->sc;              // written by the previous block's k_finish (stream order)
+    __shared__ OutPtrs s_out;             // this tile's output limits
+    const uint32_t region = a.nregions > 1 ? (blockIdx.x & (uint32_t)(a.nregions - 1)) : 0u;
     uint16_t* nlmask = reinterpret_cast<uint16_t*>(st.u.m.nlm);
     uint16_t* wsmask = reinterpret_cast<uint16_t*>(st.u.m.wsm);
 #if defined(MKT_STAMPS)
@@ -131,7 +154,13 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 #endif
 
     for (;;) {
-        if (tid == 0) { s_tile = atomicAdd(a.ticket, 1u); tile_reset(st); }
+        if (tid == 0) {
+            s_out = a.out;
+            uint32_t k = atomicAdd(a.ticket, 1u);
+            if (a.use_list) k = k < *a.defer_count ? a.defer_list[k] : 0xFFFFFFFFu;     // only the tiles the lean kernel deferred
+            s_tile = k;
+            tile_reset(st);
+        }
         __syncthreads();
         const uint32_t t = s_tile;
         if (t >= a.ntiles) break;
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
         STAMP(6);
         // ---- where do this tile's outputs go? ----------------------------------------------------
         if (a.ordered) {
-            // input order: decoupled look-back over three descriptor words, one wave each
+            // input order: decoupled look-back over three descriptor words, one wave each (single region)
             const int wv = tid >> 6;
             if (wv == 0) {
                 uint64_t ex = lookback(a.descA, t, ((uint64_t)st.sums.groups << 31) | st.sums.emitted, &a.res->err);
@@ -266,18 +295,14 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             } else if (wv == 2) {
                 uint64_t ex = lookback(a.descC, t, st.sums.sam_bytes, &a.res->err);
                 if ((tid & 63) == 0) st.base.sam_bytes = ex;
-            } else if (tid == 192) {
-                atomicAdd((unsigned long long*)&a.res->pair_bytes, (unsigned long long)st.sums.pair_bytes);
-                atomicAdd((unsigned long long*)&a.res->sam_bytes, (unsigned long long)st.sums.sam_bytes);
-                atomicAdd((unsigned long long*)&a.res->sc, (unsigned long long)st.sums.sc);
-                atomicAdd((unsigned long long*)&a.res->emitted, (unsigned long long)st.sums.emitted);
+            } else if (tid == 192) {      // totals (k_finish reads them from the region cursors in both modes)
+                if (st.sums.pair_bytes | st.sums.emitted) atomicAdd(&a.cur[0].a, (unsigned long long)st.sums.pair_bytes | ((unsigned long long)st.sums.emitted << 40));
+                if (st.sums.sam_bytes | st.sums.sc) atomicAdd(&a.cur[0].b, (unsigned long long)st.sums.sam_bytes | ((unsigned long long)st.sums.sc << 40));
             }
-        } else if (tid < 4) {
-            // any order (the reference's own order is thread-schedule dependent): one atomic range per stream
-            if (tid == 0) st.base.pair_bytes = st.sums.pair_bytes ? (uint32_t)atomicAdd((unsigned long long*)&a.res->pair_bytes, (unsigned long long)st.sums.pair_bytes) : 0u;
-            else if (tid == 1) st.base.sam_bytes = st.sums.sam_bytes ? atomicAdd((unsigned long long*)&a.res->sam_bytes, (unsigned long long)st.sums.sam_bytes) : 0ull;
-            else if (tid == 2) st.base.sc = st.sums.sc ? (uint32_t)atomicAdd((unsigned long long*)&a.res->sc, (unsigned long long)st.sums.sc) : 0u;
-            else if (st.sums.emitted) atomicAdd((unsigned long long*)&a.res->emitted, (unsigned long long)st.sums.emitted);
+        } else if (tid == 0) {
+            const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
+            st.region_id = region;
+            if (e) st.err |= e;
         }
         if (tid == 5) a.tile_groups[t] = st.sums.groups;
         __syncthreads();
@@ -285,13 +310,13 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 
         // ---- emit ------------------------------------------------------------------------------
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
-            ph_account(st, tv, P, out, t, i);
+            ph_account(st, tv, P, s_out, t, i);
             ph_last(st, &a.tile_last[t], i);
         }
         {   // .pairs bytes: one lane per output byte, coalesced stores
             const uint32_t total = st.sums.pair_bytes;
             const uint64_t go = st.base.pair_bytes;
-            if (go + total <= out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) out.pairs[go + k] = tile_pair_byte(st, tv, k); }
+            if (go + total <= s_out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) s_out.pairs[go + k] = tile_pair_byte(st, tv, k); }
             else if (tid == 0 && total) st.err |= E_PAIRS_CAP;
         }
         if (P.write_sam) {   // contiguous groups: straight byte-range copies
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
                 if ((info & (GI_EMIT | GI_CONTIG)) != (GI_EMIT | GI_CONTIG)) continue;
                 const uint32_t len = st.u.g.g_slen[i], src = st.off[i];
                 const uint64_t go = st.base.sam_bytes + st.u.g.x_sam[i];
-                if (go + len <= out.sam_cap) { for (uint32_t k = tid; k < len; k += NT) out.sam[go + k] = tv.at(src + k); }
+                if (go + len <= s_out.sam_cap) { for (uint32_t k = tid; k < len; k += NT) s_out.sam[go + k] = tv.at(src + k); }
                 else if (tid == 0) st.err |= E_SAM_CAP;
             }
         }
@@ -308,6 +333,210 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
         STAMP(8);
         if (tid < (int)C_COUNT && st.cnt[tid]) atomicAdd(&a.res->counters[tid], st.cnt[tid]);
         if (tid == 0 && st.err) atomicOr(&a.res->err, st.err);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fast: the lean tile kernel (mkt_fast.h).  Same phases as k_tiles without any generic path; a
+// tile that needs one is appended to the defer list and produces nothing here.
+typedef FastCfg<16384, 2048, 4096, 192> CfgLean;
+
+template <class Cfg>
+__global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per SIMD: four 36 KB workgroups per CU
+    __shared__ FastState<Cfg> st;
+    __shared__ ScanScratch scan;
+    __shared__ uint32_t s_tile;
+    constexpr int NVEC = (Cfg::W + 15) / 16;
+    constexpr int NM16 = Cfg::MW * 4;
+    constexpr int VPT = (NVEC + NT - 1) / NT;
+    static_assert(Cfg::LCAP <= NT, "one line per thread in the sums");
+    const int tid = threadIdx.x;
+    const Params P = a.P;
+    const uint32_t n = a.n;
+    __shared__ OutPtrs s_out;
+    const uint32_t region = blockIdx.x & (uint32_t)(a.nregions - 1);
+    uint16_t* nlmask = reinterpret_cast<uint16_t*>(st.u.m.nlm);
+    uint16_t* wsmask = reinterpret_cast<uint16_t*>(st.u.m.wsm);
+#if defined(MKT_STAMPS)
+    unsigned long long stamp_prev_ = 0;
+#endif
+
+    // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
+    for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        if (tid == 0) { s_tile = t; s_out = a.out; fast_reset(st); }
+        __syncthreads();
+        STAMP(0);
+        const TileGeom G = fast_geom<Cfg>(t, n);
+        const uint32_t wlen = G.w1 - G.w0;
+        const uint32_t nvec = (wlen + 15u) >> 4;
+        const TextView tv = fast_view(st, a.text, n, G);
+
+        // ---- stage window in LDS, build the bitmaps ------------------------------------------------
+        {
+            constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread: all loads first, then the math
+            uint4 x[LPT];
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                const uint32_t v = tid + k * NT;
+                const uint32_t go = G.w0 + (v << 4);
+                x[k] = make_uint4(0, 0, 0, 0);
+                if (v < nvec) {
+                    if (go + 16u <= n) x[k] = *reinterpret_cast<const uint4*>(a.text + go);
+                    else {
+                        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+                        for (uint32_t b = 0; go + b < n; ++b) {
+                            const uint32_t c = (uint32_t)a.text[go + b] << ((b & 3u) * 8u);
+                            if (b < 4) w0 |= c; else if (b < 8) w1 |= c; else if (b < 12) w2 |= c; else w3 |= c;
+                        }
+                        x[k] = make_uint4(w0, w1, w2, w3);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < LPT; ++k) {
+                const uint32_t v = tid + k * NT;
+                if (v >= (uint32_t)NM16) continue;
+                uint32_t mnl = 0, mws = 0;
+                if (v < nvec) {
+                    *reinterpret_cast<uint4*>(&st.win[v << 4]) = x[k];
+                    mnl = nl_bits(x[k].x) | (nl_bits(x[k].y) << 4) | (nl_bits(x[k].z) << 8) | (nl_bits(x[k].w) << 12);
+                    mws = ws_bits(x[k].x) | (ws_bits(x[k].y) << 4) | (ws_bits(x[k].z) << 8) | (ws_bits(x[k].w) << 12);
+                    const uint32_t r0 = v << 4;
+                    if (r0 + 16u > wlen) { const uint32_t keep = wlen - r0; mnl &= (1u << keep) - 1u; mws &= (1u << keep) - 1u; }
+                } else if (v == nvec && (v << 4) < (uint32_t)(Cfg::W + 16)) {
+                    *reinterpret_cast<uint4*>(&st.win[v << 4]) = make_uint4(0, 0, 0, 0);
+                }
+                nlmask[v] = (uint16_t)mnl;
+                wsmask[v] = (uint16_t)mws;
+            }
+            for (uint32_t v = tid + LPT * NT; v < (uint32_t)NM16; v += NT) { nlmask[v] = 0; wsmask[v] = 0; }   // bitmap padding
+        }
+        __syncthreads();
+        STAMP(1);
+
+        // ---- line table ----------------------------------------------------------------------------
+        {
+            auto line_bits = [&](uint32_t v) -> uint32_t {
+                uint32_t m = nlmask[v];
+                const uint32_t r0 = v << 4;
+                if (r0 + 16u > wlen - 1u) { const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u; m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u); }
+                return m;
+            };
+            uint64_t cnt = 0, dummy = 0, total, td;
+            const uint32_t v0 = tid * VPT;
+            for (uint32_t k = 0; k < (uint32_t)VPT; ++k) if (v0 + k < nvec) cnt += __popc(line_bits(v0 + k));
+            uint64_t ex = cnt;
+            block_exscan2(ex, dummy, total, td, scan);
+            const uint32_t lead = G.w0 == 0 ? 1u : 0u;
+            const uint32_t NLt = (uint32_t)total + lead;
+            if (NLt > (uint32_t)Cfg::LCAP) {
+                if (tid == 0) { st.abn = 1; st.NL = 0; }
+            } else {
+                uint32_t idx = (uint32_t)ex + lead;
+                for (uint32_t k = 0; k < (uint32_t)VPT; ++k) {
+                    if (v0 + k >= nvec) break;
+                    uint32_t m = line_bits(v0 + k);
+                    while (m) {
+                        const uint32_t b = __builtin_ctz(m);
+                        st.off16[idx++] = (uint16_t)(((v0 + k) << 4) + b + 1u);
+                        m &= m - 1u;
+                    }
+                }
+                if (tid == 0) { if (lead) st.off16[0] = 0; st.NL = NLt; st.first_idx = NLt; st.end_idx = NLt; }
+            }
+        }
+        __syncthreads();
+        const uint32_t NL = st.NL;
+        STAMP(2);
+
+        for (uint32_t i = tid; i < NL; i += NT) fast_parse(st, tv, P, G, i);
+        __syncthreads();
+        STAMP(3);
+        const uint32_t NLe = fast_nle(st);
+        const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe;
+        const uint32_t end_idx = st.end_idx < NLe ? st.end_idx : NLe;
+        if (!st.abn) for (uint32_t i = first_idx + tid; i < end_idx; i += NT) fast_group(st, tv, P, G, i);
+        __syncthreads();
+        STAMP(4);
+        STAMP(5);
+
+        // ---- tile sums: groups / emitted / self-circles / .pairs bytes per group, .sam bytes per line --
+        {
+            auto& g = st.u.g;
+            const uint32_t i = first_idx + tid;
+            uint64_t ca = 0, cb = 0;
+            uint32_t info = 0;
+            if (i < NLe && !st.abn) {
+                if (i < end_idx) {
+                    info = g.g_info[i];
+                    if (info & GI_START) ca += 1ull;
+                    if (info & GI_EMIT) ca += 1ull << 16;
+                    if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ca += 1ull << 32;
+                    cb = g.g_plen[i];
+                }
+                if (P.write_sam) cb |= (uint64_t)fast_line_sam(st, G, i) << 32;
+            }
+            uint64_t ea = ca, eb = cb, ta, tb;
+            block_exscan2(ea, eb, ta, tb, scan);
+            if (i < NLe && !st.abn) {
+                g.x_sam[i] = (uint32_t)(eb >> 32);
+                if (i < end_idx) {
+                    g.x_grp[i] = (uint8_t)(ea & 0xFFu); g.x_sc[i] = (uint8_t)((ea >> 32) & 0xFFu);
+                    g.x_pair[i] = (uint16_t)(eb & 0xFFFFu);
+                    if (info & GI_EMIT) g.em_idx[(ea >> 16) & 0xFFu] = (uint8_t)i;
+                }
+            }
+            if (tid == 0) {
+                st.sums.groups = (uint32_t)(ta & 0xFFFFu); st.sums.emitted = (uint32_t)((ta >> 16) & 0xFFFFu); st.sums.sc = (uint32_t)((ta >> 32) & 0xFFFFu);
+                st.sums.pair_bytes = (uint32_t)tb; st.sums.sam_bytes = tb >> 32;
+                if ((uint32_t)tb > 0xFFFFu) st.abn = 1;          // 16-bit in-tile offsets
+            }
+        }
+        __syncthreads();
+        STAMP(6);
+        if (st.abn) {                                         // leave the whole tile to the generic kernel
+            if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
+            __syncthreads();
+            continue;
+        }
+
+        // ---- output ranges --------------------------------------------------------------------------
+        if (tid == 0) {
+            const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
+            st.region_id = region;
+            if (e) st.abn |= e << 8;
+        } else if (tid == 4) a.tile_groups[t] = st.sums.groups;
+        __syncthreads();
+        STAMP(7);
+
+        // ---- emit ----------------------------------------------------------------------------------
+        for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
+            fast_account(st, s_out, t, i);
+            fast_last(st, &a.tile_last[t], i);
+        }
+        {
+            const uint32_t total = st.sums.pair_bytes;
+            const uint64_t go = st.base.pair_bytes;
+            if (go + total <= s_out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) s_out.pairs[go + k] = fast_pair_byte(st, tv, G, k); }
+        }
+        if (P.write_sam && st.sums.sam_bytes) {
+            const uint64_t gos = st.base.sam_bytes;
+            if (gos + st.sums.sam_bytes <= s_out.sam_cap) {
+                // one wave per emitting line, lanes stride over its bytes (window -> global)
+                const int wv = tid >> 6, lane = tid & 63;
+                for (uint32_t i = first_idx + wv; i < NLe; i += NT / 64) {
+                    if (!(st.bits[i] & LB_EMIT)) continue;
+                    const uint32_t src = st.off16[i], len = fast_line_sam(st, G, i);
+                    uint8_t* dst = s_out.sam + gos + st.u.g.x_sam[i];
+                    for (uint32_t k = lane; k < len; k += 64) dst[k] = st.win[src + k];
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(8);
+        if (tid < (int)C_COUNT && st.cnt[tid]) atomicAdd(&a.res->counters[tid], st.cnt[tid]);
+        if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
         __syncthreads();
     }
 }
@@ -342,12 +571,40 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
     if (best >= 0) atomicMax(&s_last, best);
     __syncthreads();
     BlockResult* r = a.res;
+    // totals and per-region sizes from the region cursors
+    __shared__ uint64_t s_scpre[kMaxRegions + 1];
+    if (tid == 0) {
+        uint64_t pb = 0, em = 0, sb = 0, sc = 0;
+        uint32_t err = 0;
+        for (int q = 0; q < a.nregions; ++q) {
+            const uint64_t ca = a.cur[q].a, cb = a.cur[q].b;
+            const uint64_t p = ca & kLow40, e = ca >> 40, sm = cb & kLow40, c = cb >> 40;
+            r->rpair[q] = p; r->rsam[q] = sm;
+            s_scpre[q] = sc;
+            pb += p; em += e; sb += sm; sc += c;
+            if (!a.ordered) {
+                if (p > a.pairs_rcap) err |= E_PAIRS_CAP;
+                if (sm > a.sam_rcap) err |= E_SAM_CAP;
+                if (c > a.sc_rcap) err |= E_SC_CAP;
+            }
+        }
+        s_scpre[a.nregions] = sc;
+        r->pair_bytes = pb; r->emitted = em; r->sam_bytes = sb; r->sc = sc; r->nregions = (uint32_t)a.nregions;
+        if (a.ordered) { if (pb > a.out.pairs_cap) err |= E_PAIRS_CAP; if (sb > a.out.sam_cap) err |= E_SAM_CAP; if (sc > a.out.sc_cap) err |= E_SC_CAP; }
+        if (a.run->sc + sc > a.sc_list_cap) err |= E_SC_CAP;
+        if (err) r->err |= err;
+    }
+    __syncthreads();
     const uint64_t n_sc = r->sc, sc_base = a.run->sc, g_base = a.run->groups;
     if (r->err == 0) {
-        for (uint64_t k = tid; k < n_sc; k += NTF) {
-            if (sc_base + k >= a.out.sc_cap) break;
-            const uint64_t e = a.out.sc[sc_base + k];
-            a.out.sc[sc_base + k] = g_base + a.tile_groups[(uint32_t)(e >> 32)] + (uint32_t)(e & 0xFFFFFFFFu);
+        // self-circle entries (tile, ordinal) of every region -> global group indices, appended to the run's list
+        for (int q = 0; q < a.nregions; ++q) {
+            const uint64_t cnt = s_scpre[q + 1] - s_scpre[q];
+            const uint64_t* src = a.out.sc + (uint64_t)q * (a.ordered ? 0 : a.sc_rcap);
+            for (uint64_t k = tid; k < cnt; k += NTF) {
+                const uint64_t e = src[k];
+                a.sc_list[sc_base + s_scpre[q] + k] = g_base + a.tile_groups[(uint32_t)(e >> 32)] + (uint32_t)(e & 0xFFFFFFFFu);
+            }
         }
     }
     __syncthreads();
@@ -369,6 +626,12 @@ hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
     if (cfg == CFG_SMALL) hipLaunchKernelGGL(k_tiles<CfgSmall>, dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(k_tiles<CfgFast>, dim3(grid), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+uint32_t fast_tile_bytes() { return CfgLean::TILE; }
+hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s) {
+    if (a.ntiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fast<CfgLean>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mkt_host.h"
+#include "mkt_fast.h"
 #include "mkt_synth.h"
 
 namespace mkt {
@@ -11,6 +12,12 @@ enum { CFG_FAST = 0, CFG_SMALL = 1 };
 // totals of the blocks a context has finished, kept on the device so that resident blocks chain
 // without a host round trip
 struct DevRun { uint64_t groups, sc; };
+
+// One output region's cursors, alone on a 128-byte line so that the per-tile atomics of different
+// regions never meet.  a: .pairs bytes (low 40 bits) | emitted lines (high 24); b: .sam bytes | self-circles.
+struct alignas(128) RegionCur { unsigned long long a, b; unsigned long long pad[14]; };
+constexpr int kMaxRegions = 16;
+constexpr unsigned long long kLow40 = (1ull << 40) - 1ull;
 
 struct KArgs {
     const uint8_t* text;        // block text, 16-byte aligned
@@ -24,14 +31,24 @@ struct KArgs {
     uint32_t* tile_groups;      // per tile: groups opened in it; k_finish turns it into the exclusive prefix
     int32_t ordered;            // 1: outputs in input order (decoupled look-back); 0: one atomic range per tile
     TileLast* tile_last;
+    uint32_t* defer_list;       // tiles the lean kernel left to the generic one
+    uint32_t* defer_count;
+    int32_t use_list;           // generic kernel: 1 = walk defer_list[0, *defer_count) instead of all tiles
     BlockResult* res;
     DevRun* run;
-    OutPtrs out;                // sc_base is filled by the kernel from *run
+    RegionCur* cur;             // [nregions]
+    int32_t nregions;           // 1 (ordered) or kMaxRegions
+    uint64_t pairs_rcap, sam_rcap, sc_rcap;   // capacity of one region in out.pairs / out.sam / out.sc
+    uint64_t* sc_list;          // resolved self-circle group indices of the whole run (drained by the host)
+    uint64_t sc_list_cap;
+    OutPtrs out;                // whole buffers; per-tile limits are derived from the region
     unsigned long long* stamps; // diagnostic builds only (MKT_STAMPS), else null
 };
 
 uint32_t tile_bytes(int cfg);
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s);
+hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s);
+uint32_t fast_tile_bytes();
 hipError_t launch_finish(const KArgs& a, hipStream_t s);
 
 hipError_t launch_synth_sizes(const SynParams& p, uint64_t first, uint64_t n, uint64_t* sizes, hipStream_t s);

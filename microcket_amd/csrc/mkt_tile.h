@@ -72,7 +72,8 @@ struct TileSums {
 
 struct TileLast {          // the tile's last group (quirk Q1 bookkeeping on the host)
     uint32_t counter, pair_bytes, sam_bytes, valid;
-    uint32_t pair_off, sam_off;      // where its bytes sit in the block's outputs
+    uint32_t pair_off, sam_off;      // where its bytes sit inside its output region
+    uint32_t region, pad;
 };
 
 // LDS-resident state of one tile.
@@ -107,7 +108,8 @@ struct TileState {
     uint32_t NL, first_idx, end_idx, ovf_n, err, last_line_end;
     uint32_t cnt[C_COUNT];
     TileSums sums;            // this tile's totals
-    TileSums base;            // where this tile's outputs start
+    TileSums base;            // where this tile's outputs start: ABSOLUTE positions in OutPtrs::pairs / sam / sc
+    uint32_t region_pair0, region_sam0, region_id;   // the tile's output region (TileLast offsets are region relative)
 };
 
 #if defined(__HIPCC__)
@@ -124,6 +126,7 @@ template <class Cfg> MKT_HD TextView tile_view(const TileState<Cfg>& st, const u
 
 template <class Cfg> MKT_HD void tile_reset(TileState<Cfg>& st) {
     st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.ovf_n = 0; st.err = 0; st.last_line_end = kUnknown;
+    st.region_pair0 = 0; st.region_sam0 = 0; st.region_id = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
 }
 
@@ -375,11 +378,10 @@ template <class Cfg> MKT_HD void ph_group(TileState<Cfg>& st, const TextView& tv
 }
 
 // ---- phase: account for / emit the group opened by line i ---------------------------------------
-struct OutPtrs {
+struct OutPtrs {                        // *_cap: end of the range this tile may write (its output region)
     uint8_t* pairs; uint64_t pairs_cap;
     uint8_t* sam; uint64_t sam_cap;
     uint64_t* sc; uint64_t sc_cap;      // self-circle groups: (tile << 32 | ordinal in tile), resolved to global indices by k_finish
-    uint64_t sc_base;                   // entries written by the blocks before this one
 };
 
 // slow .sam copy: surviving lines of [first line, last member end), each followed by '\n'
@@ -405,7 +407,7 @@ template <class Cfg> MKT_HD void ph_account(TileState<Cfg>& st, const TextView& 
     const uint32_t counter = info & GI_COUNTER;
     if (counter) lds_add(&st.cnt[counter], 1u);
     if (counter == C_SELFCIRCLE) {
-        uint64_t k = out.sc_base + st.base.sc + st.u.g.x_sc[i];
+        uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
         if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
         else lds_or(&st.err, E_SC_CAP);
     }
@@ -439,8 +441,9 @@ template <class Cfg> MKT_HD void ph_last(const TileState<Cfg>& st, TileLast* tl,
     tl->counter = info & GI_COUNTER;
     tl->pair_bytes = g.g_plen[i];
     tl->sam_bytes = g.g_slen[i];
-    tl->pair_off = st.base.pair_bytes + g.x_pair[i];
-    tl->sam_off = (uint32_t)(st.base.sam_bytes + g.x_sam[i]);
+    tl->pair_off = st.base.pair_bytes - st.region_pair0 + g.x_pair[i];
+    tl->sam_off = (uint32_t)(st.base.sam_bytes - st.region_sam0 + g.x_sam[i]);
+    tl->region = st.region_id; tl->pad = 0;
     tl->valid = 1;
 }
 

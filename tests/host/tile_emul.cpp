@@ -11,25 +11,88 @@
 #include <memory>
 #include <vector>
 #include "../../microcket_amd/csrc/mkt_host.h"
+#include "../../microcket_amd/csrc/mkt_fast.h"
 
 using namespace mkt;
 
+// The lean path (mkt_fast.h) for one tile, exactly as k_fast sequences it.  Returns false when the tile is
+// abnormal (deferred to the generic path); otherwise appends its outputs.
+struct LeanOut { TileSums run; };
+template <class FC>
+static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const Params& P, uint32_t t, OutPtrs& out, uint64_t sc_base,
+                      TileSums& run, std::vector<uint32_t>& tile_groups, BlockResult& res) {
+    fast_reset(st);
+    const TileGeom G = fast_geom<FC>(t, n);
+    const uint32_t wlen = G.w1 - G.w0;
+    memset(st.win, 0, sizeof st.win);
+    memcpy(st.win, text + G.w0, wlen);
+    memset(&st.u, 0, sizeof st.u);
+    for (uint32_t r = 0; r < wlen; ++r) {
+        if (st.win[r] == '\n') st.u.m.nlm[r >> 6] |= 1ull << (r & 63);
+        if (is_ws(st.win[r])) st.u.m.wsm[r >> 6] |= 1ull << (r & 63);
+    }
+    const TextView tv = fast_view(st, text, n, G);
+    uint32_t NL = 0;
+    if (G.w0 == 0) st.off16[NL++] = 0;
+    for (uint32_t r = 0; r + 1 < wlen; ++r)
+        if (st.win[r] == '\n') { if (NL == (uint32_t)FC::LCAP) return false; st.off16[NL++] = (uint16_t)(r + 1); }
+    st.NL = NL; st.first_idx = NL; st.end_idx = NL;
+    for (uint32_t i = 0; i < NL; ++i) fast_parse(st, tv, P, G, i);
+    const uint32_t NLe = fast_nle(st);
+    const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe, end_idx = st.end_idx < NLe ? st.end_idx : NLe;
+    if (!st.abn) for (uint32_t i = first_idx; i < end_idx; ++i) fast_group(st, tv, P, G, i);
+    if (st.abn) return false;
+    TileSums s = {0, 0, 0, 0, 0};
+    auto& g = st.u.g;
+    for (uint32_t i = first_idx; i < NLe; ++i) {
+        g.x_sam[i] = (uint32_t)s.sam_bytes;
+        if (i < end_idx) {
+            const uint32_t info = g.g_info[i];
+            g.x_grp[i] = (uint8_t)s.groups; g.x_sc[i] = (uint8_t)s.sc; g.x_pair[i] = (uint16_t)s.pair_bytes;
+            if (info & GI_EMIT) g.em_idx[s.emitted] = (uint8_t)i;
+            if (info & GI_START) ++s.groups;
+            if (info & GI_EMIT) ++s.emitted;
+            if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ++s.sc;
+            s.pair_bytes += g.g_plen[i];
+        }
+        if (P.write_sam) s.sam_bytes += fast_line_sam(st, G, i);
+    }
+    if (s.pair_bytes > 0xFFFFu) return false;
+    st.sums = s; st.base = run; st.base.sc += (uint32_t)sc_base;
+    while (tile_groups.size() <= t) tile_groups.push_back(0);
+    tile_groups[t] = run.groups;
+    TileLast tl = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = first_idx; i < end_idx; ++i) { fast_account(st, out, t, i); fast_last(st, &tl, i); }
+    for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = fast_pair_byte(st, tv, G, k);
+    if (P.write_sam)
+        for (uint32_t i = first_idx; i < NLe; ++i)
+            if (st.bits[i] & LB_EMIT) memcpy(out.sam + run.sam_bytes + g.x_sam[i], st.win + st.off16[i], fast_line_sam(st, G, i));
+    if (tl.valid) res.last = tl;
+    for (int c = 0; c < (int)C_COUNT; ++c) res.counters[c] += st.cnt[c];
+    run.groups += s.groups; run.emitted += s.emitted; run.sc += s.sc; run.pair_bytes += s.pair_bytes; run.sam_bytes += s.sam_bytes;
+    return true;
+}
+
 template <class Cfg>
 static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::vector<uint8_t>& pairs,
-                       std::vector<uint8_t>& sam, std::vector<uint64_t>& sc, uint64_t group_base, BlockResult& res) {
+                       std::vector<uint8_t>& sam, std::vector<uint64_t>& sc, uint64_t group_base, BlockResult& res, bool lean = false) {
     memset(&res, 0, sizeof res);
     pairs.assign((size_t)n + 4096, 0);
     sam.assign((size_t)n + 4096, 0);
     const uint64_t sc_base = sc.size();
     sc.resize(sc_base + (size_t)n / 2 + 16, 0);
-    OutPtrs out{pairs.data(), pairs.size(), sam.data(), sam.size(), sc.data(), sc.size(), sc_base};
+    OutPtrs out{pairs.data(), pairs.size(), sam.data(), sam.size(), sc.data(), sc.size()};
     std::vector<uint32_t> tile_groups;
     std::unique_ptr<TileState<Cfg>> stp(new TileState<Cfg>);
     TileState<Cfg>& st = *stp;
     TileSums run = {0, 0, 0, 0, 0};
     const uint32_t nt = num_tiles(n, Cfg::TILE);
     res.tiles = nt;
+    typedef FastCfg<Cfg::TILE, Cfg::HB, Cfg::HF, (Cfg::LCAP > 255 ? 255 : Cfg::LCAP)> FC;
+    std::unique_ptr<FastState<FC>> fstp(new FastState<FC>);
+    uint64_t lean_ok = 0;
     for (uint32_t t = 0; t < nt; ++t) {
+        if (lean && lean_tile<FC>(*fstp, text, n, P, t, out, sc_base, run, tile_groups, res)) { ++lean_ok; continue; }
         tile_reset(st);
         TileGeom G = tile_geom<Cfg>(t, n);
         const uint32_t wlen = G.w1 - G.w0;
@@ -66,8 +129,9 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
             if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ++s.sc;
             s.pair_bytes += g.g_plen[i]; s.sam_bytes += g.g_slen[i];
         }
-        st.sums = s; st.base = run;
-        tile_groups.push_back(run.groups);      // exclusive prefix, as k_finish computes it
+        st.sums = s; st.base = run; st.base.sc += (uint32_t)sc_base;
+        while (tile_groups.size() <= t) tile_groups.push_back(0);
+        tile_groups[t] = run.groups;            // exclusive prefix, as k_finish computes it
         for (uint32_t i = st.first_idx; i < st.end_idx; ++i) ph_account(st, tv, P, out, t, i);
         if (run.pair_bytes + (uint64_t)s.pair_bytes <= out.pairs_cap) {
             for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = tile_pair_byte(st, tv, k);
@@ -79,13 +143,14 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
                     if (go + st.u.g.g_slen[i] <= out.sam_cap) memcpy(out.sam + go, text + st.off[i], st.u.g.g_slen[i]);
                     else st.err |= E_SAM_CAP;
                 }
-        TileLast tl = {0, 0, 0, 0, 0, 0};
+        TileLast tl = {0, 0, 0, 0, 0, 0, 0, 0};
         for (uint32_t i = st.first_idx; i < st.end_idx; ++i) ph_last(st, &tl, i);
         if (tl.valid) res.last = tl;
         for (int c = 0; c < (int)C_COUNT; ++c) res.counters[c] += st.cnt[c];
         res.err |= st.err;
         run.groups += s.groups; run.emitted += s.emitted; run.sc += s.sc; run.pair_bytes += s.pair_bytes; run.sam_bytes += s.sam_bytes;
     }
+    res.pad = (uint32_t)lean_ok;
     res.groups = run.groups; res.emitted = run.emitted; res.sc = run.sc; res.pair_bytes = run.pair_bytes; res.sam_bytes = run.sam_bytes;
     for (uint64_t k = 0; k < run.sc; ++k) {       // what k_finish does: (tile, ordinal) -> global group index
         const uint64_t e = sc[sc_base + k];
@@ -107,7 +172,7 @@ struct EmulShard {
     std::vector<uint8_t> pairs, sam;
     std::vector<uint64_t> sc;
     uint32_t err = 0;
-    uint64_t blocks = 0;
+    uint64_t blocks = 0, lean_tiles = 0, tiles = 0;
 };
 
 static void emul_feed(EmulShard& S, const char* text, size_t n, size_t block_bytes) {
@@ -127,12 +192,14 @@ static void emul_feed(EmulShard& S, const char* text, size_t n, size_t block_byt
         }
         BlockResult r;
         const uint8_t* b = (const uint8_t*)text + pos;
-        switch (S.cfg) {
-        case 1: emul_block<CfgSafe>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
-        case 2: emul_block<CfgMid>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
-        case 3: emul_block<CfgNoHalo>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
-        default: emul_block<CfgFast>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r); break;
+        const bool lean = S.cfg >= 10;              // cfg 10 + k: lean path first, generic path for the tiles it defers
+        switch (S.cfg % 10) {
+        case 1: emul_block<CfgSafe>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
+        case 2: emul_block<CfgMid>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
+        case 3: emul_block<CfgNoHalo>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
+        default: emul_block<CfgFast>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         }
+        S.lean_tiles += r.pad; S.tiles += r.tiles;
         S.err |= r.err;
         S.acc.add_block(r);
         S.pairs.insert(S.pairs.end(), bp.begin(), bp.end());
@@ -163,7 +230,7 @@ int emul_finish(void* h, int drop_last, uint64_t group_offset, uint64_t total_gr
     *out_sam = (char*)malloc(S.sam.size() + 1); memcpy(*out_sam, S.sam.data(), S.sam.size()); *n_sam = S.sam.size();
     const int order[8] = {C_LOWMAP, C_MANYHITS, C_UNPAIRED, C_SELFCIRCLE, C_TRANS, C_CIS10K, C_CIS1K, C_CIS0};
     for (int k = 0; k < 8; ++k) counters8[k] = s.counters[order[k]];
-    stats[0] = s.groups; stats[1] = s.pairs; stats[2] = S.err; stats[3] = S.blocks;
+    stats[0] = s.groups; stats[1] = s.pairs; stats[2] = S.err; stats[3] = S.blocks | (S.lean_tiles << 20) | (S.tiles << 42);
     return 0;
 }
 void emul_close(void* h) { delete (EmulShard*)h; }

@@ -11,7 +11,8 @@ import pytest
 
 import util
 
-CFGS = {0: "fast 16K tile", 1: "small 256 B tile", 2: "mid 1K tile", 3: "2K tile, 16 B halos"}
+CFGS = {0: "fast 16K tile", 1: "small 256 B tile", 2: "mid 1K tile", 3: "2K tile, 16 B halos",
+        10: "lean path + generic for deferred tiles, 16K tile", 12: "lean + generic, 1K tile", 13: "lean + generic, 2K tile / 16 B halos"}
 
 
 def _check(text, mode, T, ratio, mapq, sam, cfg, block):
@@ -25,7 +26,7 @@ def _check(text, mode, T, ratio, mapq, sam, cfg, block):
     assert es["groups"] == st.groups, tag
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 10, 12, 13])
 @pytest.mark.parametrize("name", ["edge_unc.sam", "edge_flash.sam"])
 def test_tile_phases_edge_fixtures(name, cfg):
     text = open(os.path.join(util.GOLDEN, name), "rb").read()
@@ -35,7 +36,7 @@ def test_tile_phases_edge_fixtures(name, cfg):
                 _check(text, mode, T, ratio, mapq, sam, cfg, block)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 10, 12, 13])
 @pytest.mark.parametrize("profile,seed,groups,modes", [
     ("unc", 11, 1500, ("unc",)), ("flash", 12, 1500, ("flash",)), ("stress", 13, 4000, ("unc", "flash")),
 ])
@@ -51,13 +52,15 @@ def test_ragged_and_empty_inputs():
     for text in (b"", b"\n", b"\n\n\n", b"@HD\tVN:1.6\n", b"no newline at all", b"a\tb\n",
                  b"r1\t65\tchr1\t100\t60\t50M\t=\t1\t0\tAC\tFF\nr1\t129\tchr1\t5000\t60\t50M\t=\t1\t0\tAC\tFF\nr2\t65\tchr1\t1\t60\t5M"):
         for mode in ("unc", "flash"):
-            for cfg in (0, 1):
+            for cfg in (0, 1, 10, 13):
                 _check(text, mode, 4, 0.5, 10, True, cfg, 0)
 
 
 def test_last_line_without_newline_and_crlf():
     base = util.synth("unc", 5, 50, tail=1)
     _check(base[:-1], "unc", 4, 0.5, 10, True, 1, 0)                  # no trailing newline
+    _check(base[:-1], "unc", 4, 0.5, 10, True, 10, 0)
+    _check(base.replace(b"\n", b"\r\n"), "unc", 4, 0.5, 10, True, 12, 0)
     _check(base.replace(b"\n", b"\r\n"), "unc", 4, 0.5, 10, True, 1, 0)   # CR stays part of the last field / the .sam line
 
 
@@ -65,5 +68,5 @@ def test_long_fields_take_the_generic_parser():
     q = b"Q" * 300
     text = (q + b"\t65\tchr1\t1000\t60\t150M\t=\t1\t0\tA\tF\n" + q + b"\t129\tchrUn_" + b"x" * 200 + b"\t9000\t60\t150M\t=\t1\t0\tA\tF\n"
             + b"z\t65\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF\nz\t129\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF\n")
-    for cfg in (0, 1, 2, 3):
+    for cfg in (0, 1, 2, 3, 10, 12, 13):
         _check(text, "unc", 4, 0.5, 10, True, cfg, 0)
