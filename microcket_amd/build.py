@@ -48,11 +48,11 @@ def build_lib(force=False):
     return LIB
 
 
-def build_stamps_lib():
-    """Diagnostic build with per-phase shader-clock stamps in k_tiles (tools/phase_shares.py)."""
-    out = os.path.join(HERE, "libmkt_hip_stamps.so")
+def build_stamps_lib(name="libmkt_hip_stamps.so", defines=("-DMKT_STAMPS",)):
+    """Diagnostic builds (phase stamps / phase ladder / tile-geometry experiments); never loaded by default."""
+    out = os.path.join(HERE, name)
     srcs = [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_capi.cpp")]
-    _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-DMKT_STAMPS", "-Wno-unused-function",
+    _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", *defines, "-Wno-unused-function",
           "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", out])
     return out
 

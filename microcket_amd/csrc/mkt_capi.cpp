@@ -155,21 +155,21 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
 
 void mkt_destroy(mkt_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->p.device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : c->ev) hipEventDestroy(e);
-    if (c->d_in) hipFree(c->d_in);
-    if (c->d_pairs) hipFree(c->d_pairs);
-    if (c->d_sam) hipFree(c->d_sam);
-    if (c->d_sc) hipFree(c->d_sc);
-    if (c->d_sc_tmp) hipFree(c->d_sc_tmp);
-    if (c->d_ws) hipFree(c->d_ws);
-    if (c->d_run) hipFree(c->d_run);
-    if (c->d_syn) hipFree(c->d_syn);
-    if (c->d_syn_sizes) hipFree(c->d_syn_sizes);
-    if (c->h_in) hipHostFree(c->h_in);
-    if (c->h_res) hipHostFree(c->h_res);
-    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->p.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_sam) (void)hipFree(c->d_sam);
+    if (c->d_sc) (void)hipFree(c->d_sc);
+    if (c->d_sc_tmp) (void)hipFree(c->d_sc_tmp);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->d_run) (void)hipFree(c->d_run);
+    if (c->d_syn) (void)hipFree(c->d_syn);
+    if (c->d_syn_sizes) (void)hipFree(c->d_syn_sizes);
+    if (c->h_in) (void)hipHostFree(c->h_in);
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -229,7 +229,8 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.sc_list = c->d_sc; a.sc_list_cap = c->sc_cap;
 #if defined(MKT_STAMPS)
     if (!c->d_stamps) { HIPCHK(c, hipMalloc((void**)&c->d_stamps, 16 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_stamps, 0, 16 * sizeof(unsigned long long))); }
-    a.stamps = c->d_stamps;
+    a.stamps = getenv("MKT_NO_STAMPS") ? nullptr : c->d_stamps;
+    { const char* e = getenv("MKT_DEBUG_STOP"); a.debug_stop = e ? atoi(e) : 0; }
 #endif
     HIPCHK(c, hipMemsetAsync(c->d_ws, 0, ws_bytes_for(ntiles), c->stream));
     hipEvent_t e0, e1;
@@ -259,7 +260,7 @@ static void fold_timing(mkt_ctx* c) {       // stream must be idle
     for (size_t k = 0; k + 1 < c->ev.size(); k += 2) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]) == hipSuccess) { c->folded_ms += ms; ++c->folded_launches; c->folded_bytes += c->ev_bytes[k / 2]; }
-        hipEventDestroy(c->ev[k]); hipEventDestroy(c->ev[k + 1]);
+        (void)hipEventDestroy(c->ev[k]); (void)hipEventDestroy(c->ev[k + 1]);
     }
     c->ev.clear(); c->ev_bytes.clear();
 }
@@ -629,7 +630,7 @@ int mkt_dataset_block(const mkt_dataset* ds, uint64_t i, const void** d_text, si
 }
 void mkt_dataset_destroy(mkt_dataset* ds) {
     if (!ds) return;
-    if (ds->arena) { hipSetDevice(ds->ctx->p.device); hipFree(ds->arena); }
+    if (ds->arena) { (void)hipSetDevice(ds->ctx->p.device); (void)hipFree(ds->arena); }
     delete ds;
 }
 

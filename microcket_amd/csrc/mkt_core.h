@@ -490,6 +490,34 @@ MKT_HD uint32_t dec_digits(uint32_t v) {
 MKT_HD uint32_t pair_line_len(uint32_t qn_len, const Verdict& v) {
     return qn_len + v.chrA_len + v.chrB_len + dec_digits(v.posA) + dec_digits(v.posB) + 9u;   // 6 tabs, 2 strands, newline
 }
+// The ten decimal digits of v as ASCII, most significant first, zero padded, in two little-endian
+// words (hi8: text bytes 0..7, lo2: text bytes 8..9).  Straight-line: no data-dependent branches.
+MKT_HD void dec10(uint32_t v, uint64_t& hi8, uint32_t& lo2) {
+    uint32_t d[10];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 9; k >= 0; --k) { const uint32_t q = v / 10u; d[k] = v - q * 10u; v = q; }
+    hi8 = 0x3030303030303030ull | (uint64_t)d[0] | ((uint64_t)d[1] << 8) | ((uint64_t)d[2] << 16) | ((uint64_t)d[3] << 24) |
+          ((uint64_t)d[4] << 32) | ((uint64_t)d[5] << 40) | ((uint64_t)d[6] << 48) | ((uint64_t)d[7] << 56);
+    lo2 = 0x3030u | d[8] | (d[9] << 8);
+}
+// "<v in decimal><tail bytes>" as little-endian text in two words; tail holds ntail (<= 5) bytes.
+MKT_HD void dec_lit(uint32_t v, uint32_t ndig, uint64_t tail, uint64_t& w0, uint64_t& w1) {
+    uint64_t hi8; uint32_t lo2;
+    dec10(v, hi8, lo2);
+    // 10-byte string s = hi8 | lo2 << 64; drop the (10 - ndig) leading zeros: shift right by that many bytes
+    const uint32_t drop = 10u - ndig;                  // 0..9
+    uint64_t a, b;
+    if (drop == 0u) { a = hi8; b = lo2; }
+    else if (drop < 8u) { a = (hi8 >> (8u * drop)) | ((uint64_t)lo2 << (64u - 8u * drop)); b = drop >= 2u ? 0ull : ((uint64_t)lo2 >> (8u * drop)); }
+    else { a = (uint64_t)lo2 >> (8u * (drop - 8u)); b = 0; }
+    // append the tail at byte ndig
+    if (ndig < 8u) { a |= tail << (8u * ndig); b |= ndig >= 4u ? tail >> (64u - 8u * ndig) : 0ull; }
+    else b |= tail << (8u * (ndig - 8u));
+    w0 = a; w1 = b;
+}
+
 MKT_HD uint32_t dec_digit(uint32_t v, uint32_t from_right) {      // digit 10^from_right of v
     switch (from_right) {
     case 0: return v % 10u;

@@ -19,6 +19,7 @@ template <int TILE_, int HB_, int HF_, int LCAP_>
 struct FastCfg {
     static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
     static constexpr int MW = (W + 63) / 64 + 3;
+    static constexpr int GCAP = 96;                  // emitting groups per tile (more: generic kernel)
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
@@ -38,15 +39,19 @@ struct FastState {
     union alignas(16) Phase {
         struct { uint64_t nlm[Cfg::MW], wsm[Cfg::MW]; } m;     // while parsing
         struct {                                               // afterwards, indexed by the group's first line / by line
-            uint32_t g_info[Cfg::LCAP], g_posA[Cfg::LCAP], g_posB[Cfg::LCAP], g_slen[Cfg::LCAP];
+            uint32_t g_info[Cfg::LCAP], g_slen[Cfg::LCAP];
             uint32_t x_sam[Cfg::LCAP];                         // per LINE: offset of its bytes in the tile's .sam output
-            uint16_t g_chrA[Cfg::LCAP], g_chrB[Cfg::LCAP];     // window-relative RNAME offsets
             uint16_t g_plen[Cfg::LCAP], x_pair[Cfg::LCAP];
-            uint8_t g_chrA_len[Cfg::LCAP], g_chrB_len[Cfg::LCAP];
-            uint8_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP], em_idx[Cfg::LCAP];
+            uint8_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP], em_idx[Cfg::LCAP], g_slot[Cfg::LCAP];
+            // emitting groups only (slot = g_slot[first line]): the .pairs line as five byte runs
+            //   win[qa, +e0) | win[ca, +(e1-e0)) | litA | win[cb, +(e3-e2)) | litB
+            // (QNAME and RNAME are copied together with the tab that follows them in the SAM line)
+            uint16_t l_qa[Cfg::GCAP], l_ca[Cfg::GCAP], l_cb[Cfg::GCAP];
+            uint16_t l_e0[Cfg::GCAP], l_e1[Cfg::GCAP], l_e2[Cfg::GCAP], l_e3[Cfg::GCAP];
+            uint64_t l_litA[Cfg::GCAP][2], l_litB[Cfg::GCAP][2];   // "<posA>\t" and "<posB>\t<sA>\t<sB>\n", little-endian bytes
         } g;
     } u;
-    uint32_t NL, first_idx, end_idx, abn, last_line_end;
+    uint32_t NL, first_idx, end_idx, abn, last_line_end, nslot;
     uint32_t cnt[C_COUNT];
     TileSums sums, base;                  // base: ABSOLUTE positions in OutPtrs::pairs / sam / sc
     uint32_t region_pair0, region_sam0, region_id;
@@ -68,7 +73,7 @@ template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const u
     return tv;
 }
 template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
-    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown;
+    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown; st.nslot = 0;
     st.region_pair0 = 0; st.region_sam0 = 0; st.region_id = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
 }
@@ -104,6 +109,8 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     st.qn_off[i] = (uint8_t)r.qn_off; st.qn_len[i] = (uint8_t)r.qn_len; st.rn_off[i] = (uint8_t)r.rn_off; st.rn_len[i] = (uint8_t)r.rn_len;
     st.segCnt[i] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
     uint8_t b = r.survive ? LB_SURVIVE : 0;
+    // the emitter copies QNAME / RNAME together with the separator that follows them: it must be a tab
+    if (tv.win[off + r.qn_off + r.qn_len - G.w0] != '\t' || tv.win[off + r.rn_off + r.rn_len - G.w0] != '\t') st.abn = 1;
     if (i > 0) {
         // same QNAME token as the line before: its first token must start at its first byte
         const uint32_t poff = G.w0 + st.off16[i - 1];
@@ -116,6 +123,8 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
 
 // ---- does surviving line i open a group? ---------------------------------------------------------
 template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextView& tv, const TileGeom& G, uint32_t i) {
+    // usual case: the line before survives, and "same QNAME token as the line before" was settled while parsing
+    if (i > 0 && (st.bits[i - 1] & LB_SURVIVE)) return !(st.bits[i] & LB_EQPREV);
     bool chain = true;
     uint32_t j = i;
     for (;;) {
@@ -188,10 +197,23 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
         info |= GI_EMIT;
         if (v.sA == '-') info |= GI_SA_MINUS;
         if (v.sB == '-') info |= GI_SB_MINUS;
-        g.g_posA[i] = v.posA; g.g_posB[i] = v.posB;
-        g.g_chrA[i] = (uint16_t)(v.chrA_off - G.w0); g.g_chrB[i] = (uint16_t)(v.chrB_off - G.w0);
-        g.g_chrA_len[i] = (uint8_t)v.chrA_len; g.g_chrB_len[i] = (uint8_t)v.chrB_len;
-        g.g_plen[i] = (uint16_t)pair_line_len(st.qn_len[i], v);
+        const uint32_t slot = lds_inc(&st.nslot);
+        if (slot >= (uint32_t)Cfg::GCAP) { st.abn = 1; return; }
+        g.g_slot[i] = (uint8_t)slot;
+        const uint32_t ql = st.qn_len[i], dA = dec_digits(v.posA), dB = dec_digits(v.posB);
+        g.l_qa[slot] = (uint16_t)(st.off16[i] + st.qn_off[i]);
+        g.l_ca[slot] = (uint16_t)(v.chrA_off - G.w0); g.l_cb[slot] = (uint16_t)(v.chrB_off - G.w0);
+        const uint32_t e0 = ql + 1u, e1 = e0 + v.chrA_len + 1u, e2 = e1 + dA + 1u, e3 = e2 + v.chrB_len + 1u;
+        g.l_e0[slot] = (uint16_t)e0; g.l_e1[slot] = (uint16_t)e1; g.l_e2[slot] = (uint16_t)e2; g.l_e3[slot] = (uint16_t)e3;
+        {   // literals "<posA>\t" and "<posB>\t<sA>\t<sB>\n", text order = little-endian byte order
+            uint64_t w0, w1;
+            dec_lit(v.posA, dA, (uint64_t)'\t', w0, w1);
+            g.l_litA[slot][0] = w0; g.l_litA[slot][1] = w1;
+            const uint64_t tail = (uint64_t)'\t' | ((uint64_t)v.sA << 8) | ((uint64_t)'\t' << 16) | ((uint64_t)v.sB << 24) | ((uint64_t)'\n' << 32);
+            dec_lit(v.posB, dB, tail, w0, w1);
+            g.l_litB[slot][0] = w0; g.l_litB[slot][1] = w1;
+        }
+        g.g_plen[i] = (uint16_t)(e3 + dB + 5u);
         if (P.write_sam) {
             g.g_slen[i] = sam_bytes;
             for (uint32_t k = i; k < j; ++k) if (st.bits[k] & LB_SURVIVE) st.bits[k] |= LB_EMIT;    // members (byte-wide RMW, other bits untouched)
@@ -232,22 +254,46 @@ template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, TileLast* t
     tl->valid = 1;
 }
 
-// byte k (0 <= k < sums.pair_bytes) of the tile's .pairs output
-template <class Cfg> MKT_HD uint8_t fast_pair_byte(const FastState<Cfg>& st, const TextView& tv, const TileGeom& G, uint32_t k) {
+// Emitting group whose .pairs line holds byte k of the tile's output (ordinal in em_idx)
+template <class Cfg> MKT_HD uint32_t fast_pair_find(const FastState<Cfg>& st, uint32_t k) {
     const auto& g = st.u.g;
     uint32_t lo = 0, hi = st.sums.emitted;
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
         if (g.x_pair[g.em_idx[mid]] <= k) lo = mid; else hi = mid;
     }
-    const uint32_t i = g.em_idx[lo];
-    const uint32_t info = g.g_info[i];
-    Verdict v;
-    v.counter = info & GI_COUNTER; v.emit = true;
-    v.chrA_off = G.w0 + g.g_chrA[i]; v.chrA_len = g.g_chrA_len[i]; v.chrB_off = G.w0 + g.g_chrB[i]; v.chrB_len = g.g_chrB_len[i];
-    v.posA = g.g_posA[i]; v.posB = g.g_posB[i];
-    v.sA = (info & GI_SA_MINUS) ? '-' : '+'; v.sB = (info & GI_SB_MINUS) ? '-' : '+';
-    return pair_line_byte<true>(tv, G.w0 + st.off16[i] + st.qn_off[i], st.qn_len[i], v, k - g.x_pair[i]);
+    return lo;
+}
+// byte o of the .pairs line of the group in `slot`
+template <class Cfg> MKT_HD uint8_t fast_layout_byte(const FastState<Cfg>& st, uint32_t slot, uint32_t o) {
+    const auto& g = st.u.g;
+    const uint32_t e0 = g.l_e0[slot], e1 = g.l_e1[slot], e2 = g.l_e2[slot], e3 = g.l_e3[slot];
+    if (o < e0) return st.win[g.l_qa[slot] + o];
+    if (o < e1) return st.win[g.l_ca[slot] + (o - e0)];
+    if (o < e2) { const uint32_t r = o - e1; return (uint8_t)((r < 8u ? g.l_litA[slot][0] >> (8u * r) : g.l_litA[slot][1] >> (8u * (r - 8u))) & 0xFFu); }
+    if (o < e3) return st.win[g.l_cb[slot] + (o - e2)];
+    const uint32_t r = o - e3;
+    return (uint8_t)((r < 8u ? g.l_litB[slot][0] >> (8u * r) : g.l_litB[slot][1] >> (8u * (r - 8u))) & 0xFFu);
+}
+// byte k (0 <= k < sums.pair_bytes) of the tile's .pairs output
+template <class Cfg> MKT_HD uint8_t fast_pair_byte(const FastState<Cfg>& st, uint32_t k) {
+    const auto& g = st.u.g;
+    const uint32_t i = g.em_idx[fast_pair_find(st, k)];
+    return fast_layout_byte(st, g.g_slot[i], k - g.x_pair[i]);
+}
+// four consecutive output bytes k .. k+3 (little endian); bytes at or past `total` read as 0
+template <class Cfg> MKT_HD uint32_t fast_pair_bytes4(const FastState<Cfg>& st, uint32_t k, uint32_t total) {
+    const auto& g = st.u.g;
+    uint32_t ord = fast_pair_find(st, k);
+    uint32_t i = g.em_idx[ord], slot = g.g_slot[i], o = k - g.x_pair[i], plen = g.g_plen[i];
+    uint32_t w = 0;
+    for (uint32_t b = 0; b < 4u; ++b) {
+        if (k + b >= total) break;
+        if (o >= plen) { ++ord; i = g.em_idx[ord]; slot = g.g_slot[i]; o = 0; plen = g.g_plen[i]; }    // next line (lines are >= 14 bytes)
+        w |= (uint32_t)fast_layout_byte(st, slot, o) << (8u * b);
+        ++o;
+    }
+    return w;
 }
 
 }  // namespace mkt

@@ -13,6 +13,14 @@
 #include <hip/hip_runtime.h>
 #include "mkt_launch.h"
 
+// tile geometry of the fast configuration (the lean and the generic kernel must agree on TILE)
+#ifndef MKT_LEAN_TILE
+#define MKT_LEAN_TILE 16384
+#define MKT_LEAN_HB 2048
+#define MKT_LEAN_HF 4096
+#define MKT_LEAN_LCAP 192
+#endif
+
 namespace mkt {
 
 constexpr int NT = 256;                      // 4 waves per workgroup
@@ -32,8 +40,10 @@ struct ScanScratch { uint64_t a[NT / 64], b[NT / 64]; };
             stamp_prev_ = now_;                                                         \
         }                                                                               \
     } while (0)
+#define STOP_AFTER(k) if (a.debug_stop == (k)) { __syncthreads(); continue; }
 #else
 #define STAMP(k) do { } while (0)
+#define STOP_AFTER(k)
 #endif
 
 __device__ inline uint64_t shfl_up64(uint64_t v, int d) { return (uint64_t)__shfl_up((long long)v, d, 64); }
@@ -66,7 +76,8 @@ __device__ inline void block_exscan2(uint64_t& a, uint64_t& b, uint64_t& ta, uin
 __device__ inline uint32_t zero_bytes(uint32_t x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu); }
 // 0x80 in every byte of x that is >= n (1 <= n <= 128), bytes >= 0x80 included
 __device__ inline uint32_t ge_bytes(uint32_t x, uint32_t n) { return (((x & 0x7F7F7F7Fu) + (0x80u - n) * 0x01010101u) | x) & 0x80808080u; }
-__device__ inline uint32_t pack_msb(uint32_t z) { return ((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u); }
+// 0x80 flags of the four bytes -> bits 0..3 (one multiply gathers them: no two partial products share a bit)
+__device__ inline uint32_t pack_msb(uint32_t z) { return (((z >> 7) * 0x00204081u) >> 21) & 0xFu; }
 // per-byte masks of a dword: newline, whitespace (space, \t \n \v \f \r), one bit per byte
 __device__ inline uint32_t nl_bits(uint32_t x) { return pack_msb(zero_bytes(x ^ 0x0A0A0A0Au)); }
 __device__ inline uint32_t ws_bits(uint32_t x) {
@@ -340,7 +351,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 // ---------------------------------------------------------------------------------------------
 // k_fast: the lean tile kernel (mkt_fast.h).  Same phases as k_tiles without any generic path; a
 // tile that needs one is appended to the defer list and produces nothing here.
-typedef FastCfg<16384, 2048, 4096, 192> CfgLean;
+typedef FastCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, MKT_LEAN_LCAP> CfgLean;
 
 template <class Cfg>
 __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per SIMD: four 36 KB workgroups per CU
@@ -414,6 +425,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         }
         __syncthreads();
         STAMP(1);
+        STOP_AFTER(1)
 
         // ---- line table ----------------------------------------------------------------------------
         {
@@ -449,16 +461,21 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         __syncthreads();
         const uint32_t NL = st.NL;
         STAMP(2);
+        STOP_AFTER(2)
 
+        // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
+        const uint32_t rr_id = ((uint32_t)tid & 63u) * (NT / 64) + ((uint32_t)tid >> 6);
         for (uint32_t i = tid; i < NL; i += NT) fast_parse(st, tv, P, G, i);
         __syncthreads();
         STAMP(3);
+        STOP_AFTER(3)
         const uint32_t NLe = fast_nle(st);
         const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe;
         const uint32_t end_idx = st.end_idx < NLe ? st.end_idx : NLe;
-        if (!st.abn) for (uint32_t i = first_idx + tid; i < end_idx; i += NT) fast_group(st, tv, P, G, i);
+        if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += NT) fast_group(st, tv, P, G, i);
         __syncthreads();
         STAMP(4);
+        STOP_AFTER(4)
         STAMP(5);
 
         // ---- tile sums: groups / emitted / self-circles / .pairs bytes per group, .sam bytes per line --
@@ -495,6 +512,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         }
         __syncthreads();
         STAMP(6);
+        STOP_AFTER(6)
         if (st.abn) {                                         // leave the whole tile to the generic kernel
             if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
             __syncthreads();
@@ -509,6 +527,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         } else if (tid == 4) a.tile_groups[t] = st.sums.groups;
         __syncthreads();
         STAMP(7);
+        STOP_AFTER(7)
 
         // ---- emit ----------------------------------------------------------------------------------
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
@@ -518,18 +537,43 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         {
             const uint32_t total = st.sums.pair_bytes;
             const uint64_t go = st.base.pair_bytes;
-            if (go + total <= s_out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) s_out.pairs[go + k] = fast_pair_byte(st, tv, G, k); }
+            if (total && go + total <= s_out.pairs_cap) {
+                // one lane per 4-byte-aligned output dword; the partial dwords at both ends go out as bytes
+                uint8_t* dst = s_out.pairs + go;
+                const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);      // bytes before the first aligned dword
+                const uint32_t h = head < total ? head : total;
+                if (tid < (int)h) dst[tid] = fast_pair_byte(st, (uint32_t)tid);
+                const uint32_t ndw = (total - h + 3u) >> 2;
+                for (uint32_t d = tid; d < ndw; d += NT) {
+                    const uint32_t k = h + (d << 2);
+                    const uint32_t w = fast_pair_bytes4(st, k, total);
+                    if (k + 4u <= total) *reinterpret_cast<uint32_t*>(dst + k) = w;
+                    else for (uint32_t b = 0; k + b < total; ++b) dst[k + b] = (uint8_t)(w >> (8u * b));
+                }
+            }
         }
         if (P.write_sam && st.sums.sam_bytes) {
             const uint64_t gos = st.base.sam_bytes;
             if (gos + st.sums.sam_bytes <= s_out.sam_cap) {
-                // one wave per emitting line, lanes stride over its bytes (window -> global)
+                // one wave per emitting line: 16-byte stores on destination-aligned chunks (window bytes come
+                // through aligned LDS dwords + v_alignbyte), single bytes at the two ends
                 const int wv = tid >> 6, lane = tid & 63;
                 for (uint32_t i = first_idx + wv; i < NLe; i += NT / 64) {
                     if (!(st.bits[i] & LB_EMIT)) continue;
                     const uint32_t src = st.off16[i], len = fast_line_sam(st, G, i);
                     uint8_t* dst = s_out.sam + gos + st.u.g.x_sam[i];
-                    for (uint32_t k = lane; k < len; k += 64) dst[k] = st.win[src + k];
+                    const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
+                    const uint32_t h = head < len ? head : len;
+                    if ((uint32_t)lane < h) dst[lane] = st.win[src + lane];
+                    const uint32_t nv = (len - h) >> 4;
+                    for (uint32_t v = lane; v < nv; v += 64) {
+                        const uint32_t o = h + (v << 4);
+                        uint4 x;
+                        x.x = win_load4(tv, src + o); x.y = win_load4(tv, src + o + 4u); x.z = win_load4(tv, src + o + 8u); x.w = win_load4(tv, src + o + 12u);
+                        *reinterpret_cast<uint4*>(dst + o) = x;
+                    }
+                    const uint32_t t0 = h + (nv << 4);
+                    if ((uint32_t)lane < len - t0) dst[t0 + lane] = st.win[src + t0 + lane];
                 }
             }
         }
@@ -617,7 +661,7 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-typedef TileCfg<16384, 2048, 4096, 256, 4> CfgFast;
+typedef TileCfg<MKT_LEAN_TILE, 2048, 4096, 256, 4> CfgFast;
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
 
 uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : CfgFast::TILE; }

@@ -43,6 +43,7 @@ struct KArgs {
     uint64_t sc_list_cap;
     OutPtrs out;                // whole buffers; per-tile limits are derived from the region
     unsigned long long* stamps; // diagnostic builds only (MKT_STAMPS), else null
+    int32_t debug_stop;         // diagnostic builds only: leave every tile after phase k (timing ladder; outputs are wrong)
 };
 
 uint32_t tile_bytes(int cfg);

@@ -250,6 +250,8 @@ template <class Cfg> MKT_COLD bool start_vs_global(const TileState<Cfg>& st, con
 }
 template <class Cfg> MKT_HD bool is_start(const TileState<Cfg>& st, const TextView& tv, const Params& P, uint32_t i) {
     // precondition: line i survives
+    // usual case: the line before survives, and "same QNAME token as the line before" was settled while parsing
+    if (i > 0 && (st.bits[i - 1] & LB_SURVIVE)) return !(st.bits[i] & LB_EQPREV);
     bool chain = true;                                // every line in (j, i] has the QNAME of its predecessor
     uint32_t j = i;
     for (;;) {

@@ -63,7 +63,13 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     tile_groups[t] = run.groups;
     TileLast tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = first_idx; i < end_idx; ++i) { fast_account(st, out, t, i); fast_last(st, &tl, i); }
-    for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = fast_pair_byte(st, tv, G, k);
+    // the kernel writes aligned dwords (fast_pair_bytes4) plus byte-wise ends: exercise both forms
+    for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = fast_pair_byte(st, k);
+    for (uint32_t k = (t % 3); k < s.pair_bytes; k += 4) {
+        const uint32_t w = fast_pair_bytes4(st, k, s.pair_bytes);
+        for (uint32_t b = 0; b < 4 && k + b < s.pair_bytes; ++b)
+            if (out.pairs[run.pair_bytes + k + b] != (uint8_t)(w >> (8 * b))) { res.err |= 0x4000; }
+    }
     if (P.write_sam)
         for (uint32_t i = first_idx; i < NLe; ++i)
             if (st.bits[i] & LB_EMIT) memcpy(out.sam + run.sam_bytes + g.x_sam[i], st.win + st.off16[i], fast_line_sam(st, G, i));
