@@ -103,7 +103,8 @@ int mkt_drain(mkt_ctx* ctx, mkt_out* out);
 
 /* ---- resident path: text already in HBM (bench.py, multi-GPU shards) --------------------------
  * The block must start on a QNAME-group boundary, end on a line end, be < 1 GiB and 16-byte
- * aligned; d_text must stay valid until mkt_sync.  Output bytes stay on the device (fetch them
+ * aligned, and the memory must be readable up to the next multiple of 16 bytes past its end
+ * (the kernels load whole 16-byte vectors); d_text must stay valid until mkt_sync.  Output bytes stay on the device (fetch them
  * with mkt_fetch_last_block) and results accumulate in the context exactly as for mkt_submit.
  * The call is asynchronous on the context's stream. */
 int mkt_submit_device(mkt_ctx* ctx, const void* d_text, size_t n);

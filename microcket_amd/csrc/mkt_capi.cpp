@@ -101,7 +101,8 @@ static size_t ws_tiles_bytes(uint32_t ntiles) {
     size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + 2 * sizeof(uint32_t));
     return (b + 127) & ~(size_t)127;
 }
-static size_t ws_fixed_bytes() { return kMaxRegions * sizeof(RegionCur) + 256; }
+// fixed part: region cursors | 256 B of counters | up to 1024 scan words (1 GiB / 16 KiB / 1024 = 64 used)
+static size_t ws_fixed_bytes() { return kMaxRegions * sizeof(RegionCur) + 256 + 1024 * sizeof(uint64_t); }
 static size_t ws_bytes_for(uint32_t ntiles) { return ws_tiles_bytes(ntiles) + ws_fixed_bytes() + sizeof(BlockResult); }
 static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
     size_t need = ws_bytes_for(ntiles);
@@ -205,7 +206,10 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.ticket = (uint32_t*)w;
     a.defer_count = (uint32_t*)(w + 64);
     uint32_t* ticket2 = (uint32_t*)(w + 128);
+    a.last_tile = (int*)(w + 192);
     w += 256;
+    a.scan_desc = (uint64_t*)w; w += 1024 * sizeof(uint64_t);
+    if ((ntiles + finish_chunk_tiles() - 1) / finish_chunk_tiles() > 1024) return fail(c, MKT_E_ARG, "block has too many tiles for the finish scan");
     a.res = (BlockResult*)w;
     a.ordered = c->p.ordered ? 1 : 0;
     a.run = c->d_run;
@@ -233,6 +237,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     { const char* e = getenv("MKT_DEBUG_STOP"); a.debug_stop = e ? atoi(e) : 0; }
 #endif
     HIPCHK(c, hipMemsetAsync(c->d_ws, 0, ws_bytes_for(ntiles), c->stream));
+    HIPCHK(c, hipMemsetAsync(a.last_tile, 0xFF, sizeof(int), c->stream));
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));

@@ -190,6 +190,8 @@ MKT_HD Rec parse_record(const TextView& tv, uint32_t off, const Params& P) {
     return r;
 }
 
+MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r);      // from the window bitmaps (below)
+
 // unsigned decimal token of `len` bytes at window offset rr (all bytes inside the window)
 MKT_HD uint32_t win_parse_uint(const TextView& tv, uint32_t rr, uint32_t len, bool& ok) {
     if (len > 10u) { ok = false; return 0; }
@@ -208,20 +210,18 @@ MKT_HD uint32_t win_parse_uint(const TextView& tv, uint32_t rr, uint32_t len, bo
     return (uint32_t)v;
 }
 
-// Fast parser for a line that starts inside the window: token boundaries come from the
-// whitespace / newline bitmaps (the first 128 bytes of the line), field bytes from aligned dword
-// loads.  Returns PF_OK when r is exactly what parse_record would produce; PF_LONG when the six
-// fields do not end inside the line's first 128 bytes (the caller uses parse_record); PF_CUT when
-// the window ends before the sixth field does (the line sits at the very end of the window).
+// Fast parser for a line that starts inside the window: token boundaries come from a whitespace
+// bitmap of the line's first 128 bytes (ws0: bytes 0..63, ws1: bytes 64..127) and from L, the
+// distance from the line start to its '\n' (any value >= 128 when there is none in those bytes);
+// field bytes come from aligned dword loads.  Returns PF_OK when r is exactly what parse_record would
+// produce; PF_LONG when the six fields do not end inside the first 128 bytes (the caller uses
+// parse_record); PF_CUT when the window ends before the sixth field does.
 enum { PF_OK = 1, PF_LONG = 0, PF_CUT = -1 };
-MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r) {
+MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r, uint64_t ws0, uint64_t ws1, uint32_t L) {
     rec_clear(r, off);
     const uint32_t rr = off - tv.w0;
     if (rr >= tv.wlen) return PF_CUT;
     const uint32_t avail = tv.wlen - rr;
-    const uint64_t nl0 = bits64(tv.nlm, rr), nl1 = bits64(tv.nlm, rr + 64u);
-    const uint64_t ws0 = bits64(tv.wsm, rr), ws1 = bits64(tv.wsm, rr + 64u);
-    const uint32_t L = nl0 ? ctz64(nl0) : (nl1 ? 64u + ctz64(nl1) : 128u);      // first '\n' (bitmaps are zero past wlen)
     uint32_t lim = avail < 128u ? avail : 128u;
     if (L < lim) lim = L;
     const bool terminated = (L < 128u && lim == L) || (off + lim == tv.n);        // the line really ends at lim
@@ -259,6 +259,15 @@ MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, 
     cw.end(r);
     r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;
     return PF_OK;
+}
+
+// the same, with the head bitmaps taken from the window-wide bitmaps (generic kernel)
+MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r) {
+    const uint32_t rr = off - tv.w0;
+    if (rr >= tv.wlen) { rec_clear(r, off); return PF_CUT; }
+    const uint64_t nl0 = bits64(tv.nlm, rr), nl1 = bits64(tv.nlm, rr + 64u);
+    const uint32_t L = nl0 ? ctz64(nl0) : (nl1 ? 64u + ctz64(nl1) : 128u);      // first '\n' (bitmaps are zero past wlen)
+    return parse_record_fast(tv, off, P, r, bits64(tv.wsm, rr), bits64(tv.wsm, rr + 64u), L);
 }
 
 MKT_HD uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }

@@ -20,6 +20,7 @@ struct FastCfg {
     static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
     static constexpr int MW = (W + 63) / 64 + 3;
     static constexpr int GCAP = 96;                  // emitting groups per tile (more: generic kernel)
+    static constexpr int NV16 = (W + 15) / 16 + 8;   // 16-byte vectors of the window (+ padding)
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
@@ -37,7 +38,10 @@ struct FastState {
     uint16_t flag[Cfg::LCAP];
     uint8_t qn_off[Cfg::LCAP], qn_len[Cfg::LCAP], rn_off[Cfg::LCAP], rn_len[Cfg::LCAP], segCnt[Cfg::LCAP], bits[Cfg::LCAP];
     union alignas(16) Phase {
-        struct { uint64_t nlm[Cfg::MW], wsm[Cfg::MW]; } m;     // while parsing
+        struct {                                               // while parsing
+            uint16_t nl16[Cfg::NV16];                          // newline bits, one u16 per 16 window bytes (line table only)
+            alignas(8) uint16_t hmask[Cfg::LCAP][12];          // per line: whitespace bits of the 9 aligned 16-byte chunks that
+        } m;                                                   //   cover its first 128 bytes ([0..3], [4..7], [8] read as words)
         struct {                                               // afterwards, indexed by the group's first line / by line
             uint32_t g_info[Cfg::LCAP], g_slen[Cfg::LCAP];
             uint32_t x_sam[Cfg::LCAP];                         // per LINE: offset of its bytes in the tile's .sam output
@@ -69,7 +73,7 @@ template <class Cfg> MKT_HD TileGeom fast_geom(uint32_t tile, uint32_t n) {
 }
 template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G) {
     TextView tv;
-    tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = G.w1 - G.w0; tv.nlm = st.u.m.nlm; tv.wsm = st.u.m.wsm;
+    tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = G.w1 - G.w0; tv.nlm = nullptr; tv.wsm = nullptr;
     return tv;
 }
 template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
@@ -85,6 +89,21 @@ template <class Cfg> MKT_HD uint32_t fast_line_end(const FastState<Cfg>& st, con
     return i + 1 < st.NL ? G.w0 + st.off16[i + 1] - 1u : st.last_line_end;
 }
 
+// whitespace bits (bit b <-> byte b) of the 16 window bytes starting at window offset r0 (multiple of 16)
+MKT_HD uint32_t ws_bits16_ref(const uint8_t* win, uint32_t r0, uint32_t wlen) {
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < 16u; ++b) if (r0 + b < wlen && is_ws(win[r0 + b])) m |= 1u << b;
+    return m;
+}
+// the two 64-bit whitespace words of line i's first 128 bytes, from its head-mask row
+template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t i, uint64_t& ws0, uint64_t& ws1) {
+    const uint64_t* row = reinterpret_cast<const uint64_t*>(st.u.m.hmask[i]);
+    const uint64_t A = row[0], B = row[1], C = row[2] & 0xFFFFull;
+    const uint32_t sh = st.off16[i] & 15u;
+    ws0 = sh ? ((A >> sh) | (B << (64u - sh))) : A;
+    ws1 = sh ? ((B >> sh) | (C << (64u - sh))) : B;
+}
+
 // ---- parse line i ------------------------------------------------------------------------------
 template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
     const uint32_t off = G.w0 + st.off16[i];
@@ -97,7 +116,10 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     if (off >= G.t0 && (i == 0 || G.w0 + st.off16[i - 1] < G.t0)) st.first_idx = i;
     if (off >= G.t1 && (i == 0 || G.w0 + st.off16[i - 1] < G.t1)) st.end_idx = i;
     Rec r;
-    const int pf = parse_record_fast(tv, off, P, r);
+    uint64_t ws0, ws1;
+    fast_head_ws(st, i, ws0, ws1);
+    const uint32_t le = fast_line_end(st, G, i);                   // from the line table: no newline bitmap needed
+    const int pf = parse_record_fast(tv, off, P, r, ws0, ws1, le == kUnknown ? 0xFFFFu : le - off);
     if (pf != PF_OK) {
         if (pf == PF_CUT && off >= G.t1) st.bits[i] = LB_CUT;      // last halo line, cut by the window: ignored
         else { st.bits[i] = 0; st.abn = 1; }                       // fields beyond 128 bytes: generic kernel

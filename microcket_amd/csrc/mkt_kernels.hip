@@ -85,6 +85,21 @@ __device__ inline uint32_t ws_bits(uint32_t x) {
     return pack_msb(ctl | zero_bytes(x ^ 0x20202020u));
 }
 
+// lean kernel: the same two classifications with shared sub-expressions; 0x80 flags per byte
+__device__ inline uint32_t nl_flags(uint32_t x) {                 // byte == '\n'
+    const uint32_t y = x & 0x7F7F7F7Fu;
+    return ~((y ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu) & ~x & 0x80808080u;
+}
+__device__ inline uint32_t ws_flags(uint32_t x) {                 // byte in {9..13, 32}
+    const uint32_t y = x & 0x7F7F7F7Fu;
+    const uint32_t ctl = (y + 0x77777777u) & ~(y + 0x72727272u);  // >= 9 and not >= 14
+    const uint32_t sp = ~((y ^ 0x20202020u) + 0x7F7F7F7Fu);       // == 32
+    return (ctl | sp) & ~x & 0x80808080u;
+}
+__device__ inline uint32_t pack16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
+    return pack_msb(f0) | (pack_msb(f1) << 4) | (pack_msb(f2) << 8) | (pack_msb(f3) << 12);
+}
+
 // Decoupled look-back on one descriptor word per tile.  Executed by one full wave.
 __device__ inline uint64_t lookback(uint64_t* desc, uint32_t t, uint64_t agg, uint32_t* err_word) {
     const int lane = threadIdx.x & 63;
@@ -359,7 +374,6 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     __shared__ ScanScratch scan;
     __shared__ uint32_t s_tile;
     constexpr int NVEC = (Cfg::W + 15) / 16;
-    constexpr int NM16 = Cfg::MW * 4;
     constexpr int VPT = (NVEC + NT - 1) / NT;
     static_assert(Cfg::LCAP <= NT, "one line per thread in the sums");
     const int tid = threadIdx.x;
@@ -367,8 +381,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     const uint32_t n = a.n;
     __shared__ OutPtrs s_out;
     const uint32_t region = blockIdx.x & (uint32_t)(a.nregions - 1);
-    uint16_t* nlmask = reinterpret_cast<uint16_t*>(st.u.m.nlm);
-    uint16_t* wsmask = reinterpret_cast<uint16_t*>(st.u.m.wsm);
+    uint16_t* nlmask = st.u.m.nl16;
 #if defined(MKT_STAMPS)
     unsigned long long stamp_prev_ = 0;
 #endif
@@ -383,45 +396,39 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         const uint32_t nvec = (wlen + 15u) >> 4;
         const TextView tv = fast_view(st, a.text, n, G);
 
-        // ---- stage window in LDS, build the bitmaps ------------------------------------------------
+        // ---- stage window in LDS; newline bits (one u16 per 16 bytes) for the line table ------------
         {
-            constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread: all loads first, then the math
+            constexpr int LPT = (NVEC + 1 + NT - 1) / NT;      // 16-byte vectors per thread (+1: zero pad vector)
             uint4 x[LPT];
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {
+            for (int k = 0; k < LPT; ++k) {                    // all loads first ...
                 const uint32_t v = tid + k * NT;
                 const uint32_t go = G.w0 + (v << 4);
                 x[k] = make_uint4(0, 0, 0, 0);
-                if (v < nvec) {
-                    if (go + 16u <= n) x[k] = *reinterpret_cast<const uint4*>(a.text + go);
-                    else {
-                        uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-                        for (uint32_t b = 0; go + b < n; ++b) {
-                            const uint32_t c = (uint32_t)a.text[go + b] << ((b & 3u) * 8u);
-                            if (b < 4) w0 |= c; else if (b < 8) w1 |= c; else if (b < 12) w2 |= c; else w3 |= c;
-                        }
-                        x[k] = make_uint4(w0, w1, w2, w3);
-                    }
-                }
+                // the text buffer is readable up to the next multiple of 16 (include/mkt.h); bytes past n are cleared below
+                if (v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + go);
             }
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {
+            for (int k = 0; k < LPT; ++k) {                    // ... then the math
                 const uint32_t v = tid + k * NT;
-                if (v >= (uint32_t)NM16) continue;
-                uint32_t mnl = 0, mws = 0;
+                if (v > nvec || v >= (uint32_t)Cfg::NV16) continue;
+                uint32_t mnl = 0;
                 if (v < nvec) {
-                    *reinterpret_cast<uint4*>(&st.win[v << 4]) = x[k];
-                    mnl = nl_bits(x[k].x) | (nl_bits(x[k].y) << 4) | (nl_bits(x[k].z) << 8) | (nl_bits(x[k].w) << 12);
-                    mws = ws_bits(x[k].x) | (ws_bits(x[k].y) << 4) | (ws_bits(x[k].z) << 8) | (ws_bits(x[k].w) << 12);
                     const uint32_t r0 = v << 4;
-                    if (r0 + 16u > wlen) { const uint32_t keep = wlen - r0; mnl &= (1u << keep) - 1u; mws &= (1u << keep) - 1u; }
-                } else if (v == nvec && (v << 4) < (uint32_t)(Cfg::W + 16)) {
-                    *reinterpret_cast<uint4*>(&st.win[v << 4]) = make_uint4(0, 0, 0, 0);
+                    if (r0 + 16u > wlen) {                     // last vector of the block: clear the bytes past the end
+                        const uint32_t keep = wlen - r0;       // 1..15
+                        uint32_t* w = reinterpret_cast<uint32_t*>(&x[k]);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t lo = (uint32_t)d * 4u;
+                            w[d] = keep >= lo + 4u ? w[d] : (keep > lo ? (w[d] & ((1u << ((keep - lo) * 8u)) - 1u)) : 0u);
+                        }
+                    }
+                    mnl = pack16(nl_flags(x[k].x), nl_flags(x[k].y), nl_flags(x[k].z), nl_flags(x[k].w));
                 }
+                *reinterpret_cast<uint4*>(&st.win[v << 4]) = x[k];      // v == nvec: the zero pad vector
                 nlmask[v] = (uint16_t)mnl;
-                wsmask[v] = (uint16_t)mws;
             }
-            for (uint32_t v = tid + LPT * NT; v < (uint32_t)NM16; v += NT) { nlmask[v] = 0; wsmask[v] = 0; }   // bitmap padding
         }
         __syncthreads();
         STAMP(1);
@@ -462,6 +469,18 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         const uint32_t NL = st.NL;
         STAMP(2);
         STOP_AFTER(2)
+        // ---- whitespace bits, only where a line's six fields can be: the 9 aligned chunks over its first 128 bytes
+        for (uint32_t it = tid; it < NL * 9u; it += NT) {
+            const uint32_t i = it / 9u, c = it - i * 9u;
+            const uint32_t r0 = (st.off16[i] & ~15u) + (c << 4);
+            uint32_t m = 0;
+            if (r0 + 16u <= (uint32_t)(Cfg::W + 16)) {
+                const uint4 q = *reinterpret_cast<const uint4*>(&st.win[r0]);
+                m = pack16(ws_flags(q.x), ws_flags(q.y), ws_flags(q.z), ws_flags(q.w));
+            }
+            st.u.m.hmask[i][c] = (uint16_t)m;
+        }
+        __syncthreads();
 
         // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
         const uint32_t rr_id = ((uint32_t)tid & 63u) * (NT / 64) + ((uint32_t)tid >> 6);
@@ -585,35 +604,39 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     }
 }
 
-// After the tiles: exclusive scan of the per-tile group counts, self-circle entries resolved to
-// global group indices, the block's last group located (quirk Q1 bookkeeping happens on the host).
+// After the tiles, step 1 (one workgroup per 1024 tiles): exclusive scan of the per-tile group counts
+// (chunk prefix by the same decoupled look-back, on descA which the any-order kernels leave unused...
+// in ordered mode descA is busy, so the scan uses its own words in a.scan_desc), and the block's last
+// tile that opened a group.
 constexpr int NTF = 1024;
-__global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
+__global__ __launch_bounds__(NTF) void k_finish_scan(KArgs a) {
     __shared__ uint32_t s_wave[NTF / 64];
-    __shared__ uint32_t s_carry;
-    __shared__ int s_last;
+    __shared__ uint64_t s_pre;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { s_carry = 0; s_last = -1; }
-    __syncthreads();
-    int best = -1;
-    for (uint32_t base = 0; base < a.ntiles; base += NTF) {
-        const uint32_t t = base + tid;
-        const uint32_t x = t < a.ntiles ? a.tile_groups[t] : 0u;
-        if (t < a.ntiles && a.tile_last[t].valid) best = (int)t;
-        uint32_t inc = x;
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t t = chunk * NTF + tid;
+    const uint32_t x = t < a.ntiles ? a.tile_groups[t] : 0u;
+    if (t < a.ntiles && a.tile_last[t].valid) atomicMax(a.last_tile, (int)t);
+    uint32_t inc = x;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
-        if (lane == 63) s_wave[wv] = inc;
-        __syncthreads();
-        uint32_t pre = s_carry, tot = 0;
-        for (int w = 0; w < NTF / 64; ++w) { if (w < wv) pre += s_wave[w]; tot += s_wave[w]; }
-        if (t < a.ntiles) a.tile_groups[t] = pre + inc - x;
-        __syncthreads();
-        if (tid == 0) s_carry += tot;
-        __syncthreads();
-    }
-    if (best >= 0) atomicMax(&s_last, best);
+    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+    if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
+    uint32_t pre = 0, tot = 0;
+    for (int w = 0; w < NTF / 64; ++w) { if (w < wv) pre += s_wave[w]; tot += s_wave[w]; }
+    if (wv == 0) {
+        const uint64_t ex = lookback(a.scan_desc, chunk, (uint64_t)tot, &a.res->err);
+        if (lane == 0) s_pre = ex;
+    }
+    __syncthreads();
+    if (t < a.ntiles) a.tile_groups[t] = (uint32_t)s_pre + pre + inc - x;
+    if (chunk == gridDim.x - 1 && tid == 0) a.res->groups = s_pre + tot;
+}
+
+// step 2 (one workgroup): totals from the region cursors, self-circle entries resolved to global group
+// indices, the block's last group (quirk Q1 bookkeeping happens on the host), run totals advanced.
+__global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
+    const int tid = threadIdx.x;
     BlockResult* r = a.res;
     // totals and per-region sizes from the region cursors
     __shared__ uint64_t s_scpre[kMaxRegions + 1];
@@ -653,8 +676,8 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
     }
     __syncthreads();
     if (tid == 0) {
-        r->groups = s_carry;
-        if (s_last >= 0) r->last = a.tile_last[s_last];
+        const int last = *a.last_tile;
+        if (last >= 0) r->last = a.tile_last[last];
         r->tiles = a.ntiles;
         if (r->err == 0) { a.run->groups += r->groups; a.run->sc += n_sc; }     // a failed block is re-run
     }
@@ -679,9 +702,12 @@ hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {
+    const unsigned chunks = (a.ntiles + NTF - 1) / NTF;
+    if (chunks) hipLaunchKernelGGL(k_finish_scan, dim3(chunks), dim3(NTF), 0, s, a);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(NTF), 0, s, a);
     return hipGetLastError();
 }
+uint32_t finish_chunk_tiles() { return NTF; }
 
 // ---------------------------------------------------------------------------------------------
 // synthetic SAM: sizes, then bytes (offsets from an exclusive scan done between the two kernels)

@@ -33,6 +33,8 @@ struct KArgs {
     TileLast* tile_last;
     uint32_t* defer_list;       // tiles the lean kernel left to the generic one
     uint32_t* defer_count;
+    int* last_tile;             // highest tile index that opened a group (starts at -1)
+    uint64_t* scan_desc;        // look-back words of k_finish_scan, one per 1024 tiles
     int32_t use_list;           // generic kernel: 1 = walk defer_list[0, *defer_count) instead of all tiles
     BlockResult* res;
     DevRun* run;
@@ -50,6 +52,7 @@ uint32_t tile_bytes(int cfg);
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s);
 hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s);
 uint32_t fast_tile_bytes();
+uint32_t finish_chunk_tiles();
 hipError_t launch_finish(const KArgs& a, hipStream_t s);
 
 hipError_t launch_synth_sizes(const SynParams& p, uint64_t first, uint64_t n, uint64_t* sizes, hipStream_t s);

@@ -27,15 +27,14 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     memset(st.win, 0, sizeof st.win);
     memcpy(st.win, text + G.w0, wlen);
     memset(&st.u, 0, sizeof st.u);
-    for (uint32_t r = 0; r < wlen; ++r) {
-        if (st.win[r] == '\n') st.u.m.nlm[r >> 6] |= 1ull << (r & 63);
-        if (is_ws(st.win[r])) st.u.m.wsm[r >> 6] |= 1ull << (r & 63);
-    }
     const TextView tv = fast_view(st, text, n, G);
     uint32_t NL = 0;
     if (G.w0 == 0) st.off16[NL++] = 0;
     for (uint32_t r = 0; r + 1 < wlen; ++r)
         if (st.win[r] == '\n') { if (NL == (uint32_t)FC::LCAP) return false; st.off16[NL++] = (uint16_t)(r + 1); }
+    // head masks: whitespace bits of the 9 aligned chunks covering each line's first 128 bytes (k_fast: one lane per chunk)
+    for (uint32_t i = 0; i < NL; ++i)
+        for (uint32_t c = 0; c < 9; ++c) st.u.m.hmask[i][c] = (uint16_t)ws_bits16_ref(st.win, (st.off16[i] & ~15u) + 16u * c, wlen);
     st.NL = NL; st.first_idx = NL; st.end_idx = NL;
     for (uint32_t i = 0; i < NL; ++i) fast_parse(st, tv, P, G, i);
     const uint32_t NLe = fast_nle(st);
