@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 1
+#define MKT_ABI_VERSION 2
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -57,7 +57,15 @@ typedef struct mkt_params {
     int32_t tiles;             /* MKT_TILES_* */
     int32_t ordered;           /* 1: outputs in input order (deterministic bytes); 0 (default): any order, like the
                                 * reference, whose worker threads fwrite concurrently (sam2pairs.cpp:154,175) */
+    uint32_t extensions;       /* MKT_EXT_* bits; 0 (default) = exactly the reference's behaviour and outputs */
+    uint32_t reserved2;
 } mkt_params;
+
+/* Extensions.  NOT in the reference's sam2pairs (its only duplicate removal works on FASTQ,
+ * src/preprocess/krmdup.cpp:151-213): default off, they never change stdout / .sam / .log, parity is unpinned.
+ * MKT_EXT_KEYS makes the kernels also emit one key record per reported pair (chr1,pos1,chr2,pos2,strand1,strand2),
+ * kept on the device in input order; mkt_ext_dedup / mkt_ext_chrstat work on those after the end of the input. */
+enum { MKT_EXT_KEYS = 1 };
 
 /* The 8 counters of <prefix>.<mode>2pairs.log in file order (sam2pairs.cpp:211-218), plus totals. */
 typedef struct mkt_stats {
@@ -146,6 +154,13 @@ int mkt_dataset_create(mkt_ctx* ctx, uint64_t seed, int profile, int genome, int
 int mkt_dataset_info(const mkt_dataset* ds, uint64_t* n_blocks, uint64_t* total_bytes, uint64_t* total_groups);
 int mkt_dataset_block(const mkt_dataset* ds, uint64_t i, const void** d_text, size_t* n_bytes, uint64_t* n_groups);
 void mkt_dataset_destroy(mkt_dataset* ds);
+
+/* Pairs-level duplicate marking: a reported pair is a duplicate when an EARLIER reported pair (input order) has the
+ * same key.  flags (may be NULL) receives one byte per reported pair in input order (1 = duplicate).
+ * drop_last as in mkt_finish.  Requires MKT_EXT_KEYS. */
+int mkt_ext_dedup(mkt_ctx* ctx, int drop_last, uint64_t* total, uint64_t* dups, uint8_t* flags, size_t flags_cap);
+/* Per-chromosome contact counts of the reported pairs: lines "chrA\tchrB\tcount\n" sorted bytewise by (chrA, chrB). */
+int mkt_ext_chrstat(mkt_ctx* ctx, int drop_last, char* out, size_t cap, size_t* len);
 
 /* surviving QNAME groups seen so far (synchronises the context's stream); sharded runs exchange
  * these counts before mkt_finish */

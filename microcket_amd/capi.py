@@ -6,11 +6,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_FLASH, MODE_UNC = 0, 1
 TILES_AUTO, TILES_FAST, TILES_SMALL = 0, 1, 2
+EXT_KEYS = 1
 EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
     "mkt_submit", "mkt_drain", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
-    "mkt_reset", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
+    "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
 ]
 
 
@@ -21,7 +22,7 @@ class MktError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("mode", C.c_int32), ("min_mapped_ratio", C.c_float), ("min_mapq", C.c_int32), ("write_sam", C.c_int32),
                 ("ref_threads", C.c_int32), ("device", C.c_int32), ("block_bytes", C.c_uint64), ("tiles", C.c_int32),
-                ("ordered", C.c_int32)]
+                ("ordered", C.c_int32), ("extensions", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -87,6 +88,8 @@ def load_library():
     L.mkt_dataset_destroy.argtypes = [C.c_void_p]
     L.mkt_dataset_destroy.restype = None
     L.mkt_reset.argtypes = [C.c_void_p]
+    L.mkt_ext_dedup.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
+    L.mkt_ext_chrstat.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.mkt_group_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
@@ -100,11 +103,11 @@ class Context:
     """One GPU context = one input stream (mirrors one bin/sam2pairs process of the reference)."""
 
     def __init__(self, mode, ratio=0.5, min_mapq=10, write_sam=True, ref_threads=4, device=0, block_bytes=0, tiles=TILES_AUTO,
-                 ordered=False):
+                 ordered=False, extensions=0):
         self.L = load_library()
         if isinstance(mode, str):
             mode = {"flash": MODE_FLASH, "unc": MODE_UNC}[mode]
-        self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 1 if ordered else 0)
+        self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 1 if ordered else 0, extensions, 0)
         self.h = C.c_void_p()
         rc = self.L.mkt_create(C.byref(self.params), C.byref(self.h))
         if rc != 0:
@@ -197,6 +200,23 @@ class Context:
 
     def reset(self):
         self._chk(self.L.mkt_reset(self.h), "mkt_reset")
+
+    def ext_dedup(self, drop_last=True, want_flags=True):
+        """(total reported pairs, duplicates, flags bytes in input order)"""
+        tot, dup = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.mkt_ext_dedup(self.h, 1 if drop_last else 0, C.byref(tot), C.byref(dup), None, 0), "mkt_ext_dedup")
+        if not want_flags or tot.value == 0:
+            return tot.value, dup.value, b""
+        buf = C.create_string_buffer(tot.value)
+        self._chk(self.L.mkt_ext_dedup(self.h, 1 if drop_last else 0, C.byref(tot), C.byref(dup), buf, tot.value), "mkt_ext_dedup")
+        return tot.value, dup.value, buf.raw[:tot.value]
+
+    def ext_chrstat(self, drop_last=True):
+        n = C.c_size_t()
+        self._chk(self.L.mkt_ext_chrstat(self.h, 1 if drop_last else 0, None, 0, C.byref(n)), "mkt_ext_chrstat")
+        buf = C.create_string_buffer(max(n.value, 1))
+        self._chk(self.L.mkt_ext_chrstat(self.h, 1 if drop_last else 0, buf, n.value, C.byref(n)), "mkt_ext_chrstat")
+        return buf.raw[:n.value]
 
     def group_count(self):
         g = C.c_uint64()

@@ -6,7 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/mkt.h"
@@ -28,6 +30,10 @@ struct mkt_ctx {
     uint8_t* d_sam = nullptr; size_t sam_cap = 0;
     uint64_t* d_sc = nullptr; size_t sc_cap = 0;          // the run's resolved self-circle list (drained at syncs)
     uint64_t* d_sc_tmp = nullptr; size_t sc_tmp_cap = 0;  // per block: raw (tile, ordinal) entries, one slice per region
+    // extensions (MKT_EXT_KEYS)
+    KeyRec* d_keys_raw = nullptr; size_t keys_raw_cap = 0; // per block, one slice per region
+    KeyRec* d_key_list = nullptr; size_t key_list_cap = 0; // the run's keys in input order
+    ChrTab* d_chr = nullptr;
     uint8_t* d_ws = nullptr; size_t ws_cap = 0;
     DevRun* d_run = nullptr;
     // host (pinned)
@@ -41,6 +47,7 @@ struct mkt_ctx {
     bool input_done = false, finished = false;
     uint64_t bytes_in = 0, blocks = 0;
     size_t last_n = 0;                   // bytes of the last resident block
+    uint64_t keys_upper = 0;             // upper bound of the key records enqueued so far (extension)
     uint64_t sc_on_device = 0;           // self-circle entries of folded blocks still in d_sc
     uint64_t bytes_unsynced = 0;         // resident bytes enqueued since the last sync
     // timing
@@ -98,7 +105,7 @@ int mkt_device_count(void) {
 // workspace of one block: descA | descB | descC | tile_last | tile_groups | defer_list |
 //                         region cursors (16 x 128 B) | ticket, defer_count, ticket of the deferred pass (256 B) | BlockResult
 static size_t ws_tiles_bytes(uint32_t ntiles) {
-    size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + 2 * sizeof(uint32_t));
+    size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + sizeof(uint64_t) + sizeof(uint32_t));
     return (b + 127) & ~(size_t)127;
 }
 // fixed part: region cursors | 256 B of counters | up to 1024 scan words (1 GiB / 16 KiB / 1024 = 64 used)
@@ -164,6 +171,9 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_sam) (void)hipFree(c->d_sam);
     if (c->d_sc) (void)hipFree(c->d_sc);
     if (c->d_sc_tmp) (void)hipFree(c->d_sc_tmp);
+    if (c->d_keys_raw) (void)hipFree(c->d_keys_raw);
+    if (c->d_key_list) (void)hipFree(c->d_key_list);
+    if (c->d_chr) (void)hipFree(c->d_chr);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_run) (void)hipFree(c->d_run);
     if (c->d_syn) (void)hipFree(c->d_syn);
@@ -199,7 +209,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.descB = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.descC = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.tile_last = (TileLast*)w; w += (size_t)ntiles * sizeof(TileLast);
-    a.tile_groups = (uint32_t*)w; w += (size_t)ntiles * sizeof(uint32_t);
+    a.tile_groups = (uint64_t*)w; w += (size_t)ntiles * sizeof(uint64_t);
     a.defer_list = (uint32_t*)w;
     w = c->d_ws + ws_tiles_bytes(ntiles);
     a.cur = (RegionCur*)w; w += kMaxRegions * sizeof(RegionCur);
@@ -231,6 +241,32 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.out.sam = c->d_sam; a.out.sam_cap = c->P.write_sam ? c->sam_cap : 0;
     a.out.sc = c->d_sc_tmp; a.out.sc_cap = c->sc_tmp_cap;
     a.sc_list = c->d_sc; a.sc_list_cap = c->sc_cap;
+    if (c->p.extensions & MKT_EXT_KEYS) {
+        if (!c->d_chr) { HIPCHK(c, hipMalloc((void**)&c->d_chr, sizeof(ChrTab))); HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream)); }
+        // at most one reported pair per two 32-byte lines; twice that per region for imbalance
+        const size_t per = (n / 64 / (size_t)a.nregions) * 2 + 4096, need = per * a.nregions;
+        if (c->keys_raw_cap < need) {
+            if (c->d_keys_raw) HIPCHK(c, hipFree(c->d_keys_raw));
+            c->d_keys_raw = nullptr; c->keys_raw_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->d_keys_raw, need * sizeof(KeyRec)));
+            c->keys_raw_cap = need;
+        }
+        // the run's list grows by doubling (the stream is idle whenever it has to: growth syncs)
+        const size_t want = (size_t)c->keys_upper + n / 64 + 4096;
+        if (c->key_list_cap < want) {
+            size_t ncap = c->key_list_cap ? c->key_list_cap * 2 : ((size_t)1 << 22);
+            while (ncap < want) ncap *= 2;
+            KeyRec* nl = nullptr;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            HIPCHK(c, hipMalloc((void**)&nl, ncap * sizeof(KeyRec)));
+            if (c->d_key_list) { HIPCHK(c, hipMemcpy(nl, c->d_key_list, c->key_list_cap * sizeof(KeyRec), hipMemcpyDeviceToDevice)); HIPCHK(c, hipFree(c->d_key_list)); }
+            c->d_key_list = nl; c->key_list_cap = ncap;
+        }
+        c->keys_upper += n / 64 + 1;
+        a.keys_rcap = c->keys_raw_cap / a.nregions;
+        a.out.keys = c->d_keys_raw; a.out.keys_cap = c->keys_raw_cap; a.out.chr = c->d_chr;
+        a.key_list = c->d_key_list; a.key_list_cap = c->key_list_cap;
+    }
 #if defined(MKT_STAMPS)
     if (!c->d_stamps) { HIPCHK(c, hipMalloc((void**)&c->d_stamps, 16 * sizeof(unsigned long long))); HIPCHK(c, hipMemset(c->d_stamps, 0, 16 * sizeof(unsigned long long))); }
     a.stamps = getenv("MKT_NO_STAMPS") ? nullptr : c->d_stamps;
@@ -497,6 +533,78 @@ int mkt_finish(mkt_ctx* c, int drop_last, uint64_t group_offset, uint64_t total_
     return MKT_OK;
 }
 
+// ---- extensions ---------------------------------------------------------------------------------
+static uint64_t ext_key_count(mkt_ctx* c, int drop_last) {
+    uint64_t n = c->acc.emitted;
+    if (drop_last && c->acc.pending.valid && c->acc.pending.pair_bytes && n) --n;     // quirk Q1: the input's last group reported a pair
+    return n;
+}
+int mkt_ext_dedup(mkt_ctx* c, int drop_last, uint64_t* total, uint64_t* dups, uint8_t* flags, size_t flags_cap) {
+    if (!c) return MKT_E_ARG;
+    if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    const uint64_t n = ext_key_count(c, drop_last);
+    if (total) *total = n;
+    if (dups) *dups = 0;
+    if (n == 0) return MKT_OK;
+    if (flags && flags_cap < n) return fail(c, MKT_E_ARG, "flags buffer too small (%llu needed)", (unsigned long long)n);
+    uint8_t* d_flags = nullptr; void* d_work = nullptr; DedupResult* d_res = nullptr;
+    const size_t wb = dedup_work_bytes(n);
+    HIPCHK(c, hipMalloc((void**)&d_flags, n));
+    HIPCHK(c, hipMalloc(&d_work, wb));
+    HIPCHK(c, hipMalloc((void**)&d_res, sizeof(DedupResult)));
+    HIPCHK(c, launch_dedup(c->d_key_list, n, d_flags, d_work, wb, d_res, c->stream));
+    DedupResult r;
+    HIPCHK(c, hipMemcpyAsync(&r, d_res, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    if (flags) HIPCHK(c, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_flags); (void)hipFree(d_work); (void)hipFree(d_res);
+    if (dups) *dups = r.dups;
+    return MKT_OK;
+}
+int mkt_ext_chrstat(mkt_ctx* c, int drop_last, char* out, size_t cap, size_t* len) {
+    if (!c || !len) return MKT_E_ARG;
+    if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    *len = 0;
+    const uint64_t n = ext_key_count(c, drop_last);
+    if (n == 0 || !c->d_chr) return MKT_OK;
+    // the name table -> dense ids in bytewise name order
+    std::vector<unsigned long long> hh(kChrSlots);
+    std::vector<uint8_t> names((size_t)kChrSlots * 64);
+    HIPCHK(c, hipMemcpy(hh.data(), c->d_chr->hash, kChrSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(names.data(), c->d_chr->name, names.size(), hipMemcpyDeviceToHost));
+    std::vector<std::pair<std::string, uint32_t>> used;
+    for (uint32_t s2 = 0; s2 < kChrSlots; ++s2) if (hh[s2]) used.emplace_back(std::string((const char*)&names[(size_t)s2 * 64], names[(size_t)s2 * 64 + 63]), s2);
+    std::sort(used.begin(), used.end());
+    const uint32_t nd = (uint32_t)used.size();
+    std::vector<uint16_t> dense(kChrSlots, 0);
+    for (uint32_t d = 0; d < nd; ++d) dense[used[d].second] = (uint16_t)d;
+    uint16_t* d_dense = nullptr; unsigned long long* d_counts = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d_dense, kChrSlots * sizeof(uint16_t)));
+    HIPCHK(c, hipMalloc((void**)&d_counts, (size_t)nd * nd * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemcpyAsync(d_dense, dense.data(), kChrSlots * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_counts, 0, (size_t)nd * nd * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, launch_chrstat(c->d_key_list, n, d_dense, nd, d_counts, c->stream));
+    std::vector<unsigned long long> counts((size_t)nd * nd);
+    HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_dense); (void)hipFree(d_counts);
+    std::string txt;
+    char num[32];
+    for (uint32_t a2 = 0; a2 < nd; ++a2)
+        for (uint32_t b2 = 0; b2 < nd; ++b2)
+            if (counts[(size_t)a2 * nd + b2]) {
+                snprintf(num, sizeof num, "%llu", counts[(size_t)a2 * nd + b2]);
+                txt += used[a2].first; txt += '\t'; txt += used[b2].first; txt += '\t'; txt += num; txt += '\n';
+            }
+    *len = txt.size();
+    if (out) { if (cap < txt.size()) return fail(c, MKT_E_ARG, "chrstat buffer too small (%zu needed)", txt.size()); memcpy(out, txt.data(), txt.size()); }
+    return MKT_OK;
+}
+
 int mkt_reset(mkt_ctx* c) {
     if (!c) return MKT_E_ARG;
     HIPCHK(c, hipSetDevice(c->p.device));
@@ -505,7 +613,8 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
-    c->sc_host.clear(); c->sc_on_device = 0; c->bytes_unsynced = 0;
+    c->sc_host.clear(); c->sc_on_device = 0; c->bytes_unsynced = 0; c->keys_upper = 0;
+    if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;
     c->out_pairs.clear(); c->out_sam.clear(); c->tail_pairs.clear(); c->tail_sam.clear();

@@ -573,6 +573,27 @@ MKT_HD uint8_t pair_line_byte(const TextView& tv, uint32_t qn_abs, uint32_t qn_l
     }
 }
 
+// ---- extensions (default off; parity unpinned by the reference) ----------------
+// One record per emitted pair: the duplicate-marking key (chr1, pos1, chr2, pos2, strand1, strand2) with
+// chromosome NAMES replaced by their slot in the run's name table (64-bit FNV-1a keyed, see chr_slot).
+struct KeyRec {
+    uint64_t k0;       // chrA slot << 45 | chrB slot << 32 | posA
+    uint64_t k1;       // posB << 32 | sA('-') << 31 | sB('-') << 30
+    uint64_t ord;      // raw: tile << 16 | emit ordinal in tile ; placed: emitted-pair ordinal in input order
+};
+constexpr uint32_t kChrSlots = 8192;               // open addressing, power of two
+constexpr uint32_t kChrNameMax = 62;
+struct ChrTab {
+    unsigned long long hash[kChrSlots];            // 0 = empty
+    uint8_t name[kChrSlots][64];                   // written by the thread that claimed the slot; [63] = length; read by the host only
+};
+MKT_HD uint64_t fnv1a64(const TextView& tv, uint32_t off, uint32_t len) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint32_t i = 0; i < len; ++i) { h ^= tv.at(off + i); h *= 0x100000001b3ull; }
+    return h ? h : 1ull;
+}
+MKT_HD uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+
 // Quirk Q2: does surviving group g of K contribute to the LOGGED selfCircle?
 MKT_HD bool selfcircle_logged(uint64_t g, uint64_t K, uint32_t ref_threads) {
     uint64_t j = g / kRefBatch, i = g % kRefBatch;

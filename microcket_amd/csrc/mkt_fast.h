@@ -46,7 +46,8 @@ struct FastState {
             uint32_t g_info[Cfg::LCAP], g_slen[Cfg::LCAP];
             uint32_t x_sam[Cfg::LCAP];                         // per LINE: offset of its bytes in the tile's .sam output
             uint16_t g_plen[Cfg::LCAP], x_pair[Cfg::LCAP];
-            uint8_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP], em_idx[Cfg::LCAP], g_slot[Cfg::LCAP];
+            uint8_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP], x_emit[Cfg::LCAP], em_idx[Cfg::LCAP], g_slot[Cfg::LCAP];
+            uint32_t l_posA[Cfg::GCAP], l_posB[Cfg::GCAP];     // extension (key records) only
             // emitting groups only (slot = g_slot[first line]): the .pairs line as five byte runs
             //   win[qa, +e0) | win[ca, +(e1-e0)) | litA | win[cb, +(e3-e2)) | litB
             // (QNAME and RNAME are copied together with the tab that follows them in the SAM line)
@@ -227,6 +228,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
         g.l_ca[slot] = (uint16_t)(v.chrA_off - G.w0); g.l_cb[slot] = (uint16_t)(v.chrB_off - G.w0);
         const uint32_t e0 = ql + 1u, e1 = e0 + v.chrA_len + 1u, e2 = e1 + dA + 1u, e3 = e2 + v.chrB_len + 1u;
         g.l_e0[slot] = (uint16_t)e0; g.l_e1[slot] = (uint16_t)e1; g.l_e2[slot] = (uint16_t)e2; g.l_e3[slot] = (uint16_t)e3;
+        g.l_posA[slot] = v.posA; g.l_posB[slot] = v.posB;
         {   // literals "<posA>\t" and "<posB>\t<sA>\t<sB>\n", text order = little-endian byte order
             uint64_t w0, w1;
             dec_lit(v.posA, dA, (uint64_t)'\t', w0, w1);
@@ -260,6 +262,20 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
         uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
         if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
         else st.abn = E_SC_CAP << 8;                  // reported as an error bit by the kernel
+    }
+    if ((info & GI_EMIT) && out.keys) {               // extension: duplicate-marking key of this pair
+        const auto& g = st.u.g;
+        const uint32_t slot = g.g_slot[i];
+        const uint64_t k = (uint64_t)st.base.emitted + g.x_emit[i];
+        if (k < out.keys_cap) {
+            TextView tv;
+            tv.g = nullptr; tv.n = 0; tv.win = st.win; tv.w0 = 0; tv.wlen = Cfg::W + 16; tv.nlm = nullptr; tv.wsm = nullptr;
+            uint32_t err = 0;
+            const uint32_t sa = chr_slot(out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
+            const uint32_t sb = chr_slot(out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
+            out.keys[k] = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i]);
+            if (err) st.abn = err << 8;
+        } else st.abn = E_SC_CAP << 8;
     }
 }
 template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, TileLast* tl, uint32_t i) {

@@ -152,6 +152,8 @@ __device__ inline uint32_t claim_ranges(const KArgs& a, uint32_t region, const T
     if (os + sums.sam_bytes > a.sam_rcap) err |= E_SAM_CAP;
     if (oc + sums.sc > a.sc_rcap) err |= E_SC_CAP;
     base.pair_bytes = (uint32_t)(p0 + op); base.sam_bytes = s0 + os; base.sc = (uint32_t)(c0 + oc);
+    base.emitted = (uint32_t)((uint64_t)region * a.keys_rcap + (oa >> 40));           // extension: slot of the tile's first key record
+    lim.keys_cap = a.keys_rcap ? ((uint64_t)region * a.keys_rcap + ((oa >> 40) + sums.emitted <= a.keys_rcap ? a.keys_rcap : 0)) : 0;
     region_pair0 = (uint32_t)p0; region_sam0 = (uint32_t)s0;
     lim.pairs_cap = err & E_PAIRS_CAP ? 0 : p0 + a.pairs_rcap;     // an overflowing tile writes nothing
     lim.sam_cap = err & E_SAM_CAP ? 0 : s0 + a.sam_rcap;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             for (uint32_t k = 0; k < (uint32_t)IPT; ++k) {
                 const uint32_t i = i0 + k;
                 if (i >= end_idx) break;
-                g.x_grp[i] = (uint16_t)(ea & 0xFFFFu); g.x_sc[i] = (uint16_t)((ea >> 32) & 0xFFFFu);
+                g.x_grp[i] = (uint16_t)(ea & 0xFFFFu); g.x_sc[i] = (uint16_t)((ea >> 32) & 0xFFFFu); g.x_emit[i] = (uint16_t)((ea >> 16) & 0xFFFFu);
                 g.x_pair[i] = (uint32_t)eb; g.x_sam[i] = (uint32_t)(eb >> 32);
                 const uint32_t info = g.g_info[i];
                 if (info & GI_EMIT) g.em_idx[(ea >> 16) & 0xFFFFu] = (uint16_t)i;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             st.region_id = region;
             if (e) st.err |= e;
         }
-        if (tid == 5) a.tile_groups[t] = st.sums.groups;
+        if (tid == 5) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
         __syncthreads();
         STAMP(7);
 
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             if (i < NLe && !st.abn) {
                 g.x_sam[i] = (uint32_t)(eb >> 32);
                 if (i < end_idx) {
-                    g.x_grp[i] = (uint8_t)(ea & 0xFFu); g.x_sc[i] = (uint8_t)((ea >> 32) & 0xFFu);
+                    g.x_grp[i] = (uint8_t)(ea & 0xFFu); g.x_sc[i] = (uint8_t)((ea >> 32) & 0xFFu); g.x_emit[i] = (uint8_t)((ea >> 16) & 0xFFu);
                     g.x_pair[i] = (uint16_t)(eb & 0xFFFFu);
                     if (info & GI_EMIT) g.em_idx[(ea >> 16) & 0xFFu] = (uint8_t)i;
                 }
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
             st.region_id = region;
             if (e) st.abn |= e << 8;
-        } else if (tid == 4) a.tile_groups[t] = st.sums.groups;
+        } else if (tid == 4) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
         __syncthreads();
         STAMP(7);
         STOP_AFTER(7)
@@ -610,27 +612,28 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
 // tile that opened a group.
 constexpr int NTF = 1024;
 __global__ __launch_bounds__(NTF) void k_finish_scan(KArgs a) {
-    __shared__ uint32_t s_wave[NTF / 64];
+    __shared__ uint64_t s_wave[NTF / 64];
     __shared__ uint64_t s_pre;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = chunk * NTF + tid;
-    const uint32_t x = t < a.ntiles ? a.tile_groups[t] : 0u;
+    const uint64_t x = t < a.ntiles ? a.tile_groups[t] : 0ull;       // groups | emitted << 32
     if (t < a.ntiles && a.tile_last[t].valid) atomicMax(a.last_tile, (int)t);
-    uint32_t inc = x;
+    uint64_t inc = x;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(inc, d, 64); if (lane >= d) inc += y; }
+    for (int d = 1; d < 64; d <<= 1) { uint64_t y = shfl_up64(inc, d); if (lane >= d) inc += y; }
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
-    uint32_t pre = 0, tot = 0;
+    uint64_t pre = 0, tot = 0;
     for (int w = 0; w < NTF / 64; ++w) { if (w < wv) pre += s_wave[w]; tot += s_wave[w]; }
     if (wv == 0) {
-        const uint64_t ex = lookback(a.scan_desc, chunk, (uint64_t)tot, &a.res->err);
-        if (lane == 0) s_pre = ex;
+        // payload: groups (31 bits) | emitted (31 bits)
+        const uint64_t ex = lookback(a.scan_desc, chunk, ((tot & 0x7FFFFFFFull) << 31) | (tot >> 32), &a.res->err);
+        if (lane == 0) s_pre = (ex >> 31) | ((ex & 0x7FFFFFFFull) << 32);
     }
     __syncthreads();
-    if (t < a.ntiles) a.tile_groups[t] = (uint32_t)s_pre + pre + inc - x;
-    if (chunk == gridDim.x - 1 && tid == 0) a.res->groups = s_pre + tot;
+    if (t < a.ntiles) a.tile_groups[t] = s_pre + pre + inc - x;
+    if (chunk == gridDim.x - 1 && tid == 0) a.res->groups = (s_pre + tot) & 0xFFFFFFFFull;
 }
 
 // step 2 (one workgroup): totals from the region cursors, self-circle entries resolved to global group
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
             const uint64_t* src = a.out.sc + (uint64_t)q * (a.ordered ? 0 : a.sc_rcap);
             for (uint64_t k = tid; k < cnt; k += NTF) {
                 const uint64_t e = src[k];
-                a.sc_list[sc_base + s_scpre[q] + k] = g_base + a.tile_groups[(uint32_t)(e >> 32)] + (uint32_t)(e & 0xFFFFFFFFu);
+                a.sc_list[sc_base + s_scpre[q] + k] = g_base + (a.tile_groups[(uint32_t)(e >> 32)] & 0xFFFFFFFFull) + (uint32_t)(e & 0xFFFFFFFFu);
             }
         }
     }
@@ -679,8 +682,30 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
         const int last = *a.last_tile;
         if (last >= 0) r->last = a.tile_last[last];
         r->tiles = a.ntiles;
-        if (r->err == 0) { a.run->groups += r->groups; a.run->sc += n_sc; }     // a failed block is re-run
+        if (a.keys_rcap && a.run->emitted + r->emitted > a.key_list_cap) r->err |= E_SC_CAP;
     }
+}
+
+// step 3 (extension, many workgroups): the block's raw key records -> the run's key list, at their
+// emitted-pair ordinal in INPUT order (run total + tile prefix + ordinal in tile); then the run totals advance.
+__global__ void k_keys_place(KArgs a) {
+    const BlockResult* r = a.res;
+    if (r->err) return;
+    const uint64_t base = a.run->emitted;
+    for (int q = 0; q < a.nregions; ++q) {
+        const uint64_t cnt = a.cur[q].a >> 40;
+        const KeyRec* src = a.out.keys + (uint64_t)q * (a.ordered ? 0 : a.keys_rcap);
+        for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * blockDim.x) {
+            KeyRec rec = src[k];
+            const uint64_t ord = base + (a.tile_groups[(uint32_t)(rec.ord >> 16)] >> 32) + (rec.ord & 0xFFFFu);
+            rec.ord = ord;
+            a.key_list[ord] = rec;
+        }
+    }
+}
+__global__ void k_run_advance(KArgs a) {
+    BlockResult* r = a.res;
+    if (threadIdx.x == 0 && r->err == 0) { a.run->groups += r->groups; a.run->sc += r->sc; a.run->emitted += r->emitted; }     // a failed block is re-run
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -705,9 +730,150 @@ hipError_t launch_finish(const KArgs& a, hipStream_t s) {
     const unsigned chunks = (a.ntiles + NTF - 1) / NTF;
     if (chunks) hipLaunchKernelGGL(k_finish_scan, dim3(chunks), dim3(NTF), 0, s, a);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(NTF), 0, s, a);
+    if (a.keys_rcap) hipLaunchKernelGGL(k_keys_place, dim3(256), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_run_advance, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 uint32_t finish_chunk_tiles() { return NTF; }
+
+// ---------------------------------------------------------------------------------------------
+// Extension A9: duplicate marking over the run's key list (input order).  A pair is a duplicate when
+// an EARLIER pair has the same (chr1, pos1, chr2, pos2, strand1, strand2).  Hand-written LSD radix
+// sort of (40-bit key hash, index) records -- 4-bit digits, ballot ranking, stable -- then every
+// element looks back inside its equal-hash run for an equal FULL key (exact; hash ties only cost time).
+constexpr int DD_BITS = 40, DD_PASSES = DD_BITS / 4, DD_WG = 256;
+constexpr uint64_t kKeyMask1 = 0xFFFFFFFFC0000000ull;          // posB + the two strand bits of KeyRec::k1
+
+__device__ inline bool key_eq(const KeyRec& x, const KeyRec& y) { return x.k0 == y.k0 && (x.k1 & kKeyMask1) == (y.k1 & kKeyMask1); }
+
+__global__ void k_dd_init(const KeyRec* keys, uint64_t n, uint64_t* h, uint32_t* idx) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        h[j] = mix64(keys[j].k0 ^ mix64(keys[j].k1 & kKeyMask1)) >> (64 - DD_BITS);
+        idx[j] = (uint32_t)j;
+    }
+}
+__global__ __launch_bounds__(DD_WG) void k_dd_hist(const uint64_t* h, uint64_t n, uint64_t per, int shift, uint32_t* hist, uint32_t G) {
+    __shared__ uint32_t cnt[16];
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j = b + threadIdx.x; j < e; j += DD_WG) atomicAdd(&cnt[(h[j] >> shift) & 15u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 16) hist[threadIdx.x * G + blockIdx.x] = cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(NT) void k_dd_scan(uint32_t* hist, uint32_t m) {       // exclusive scan of m counters, one workgroup
+    __shared__ ScanScratch sc;
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < m; base += NT) {
+        const uint32_t i = base + threadIdx.x;
+        uint64_t x = i < m ? hist[i] : 0, d = 0, tx, td, e = x;
+        block_exscan2(e, d, tx, td, sc);
+        if (i < m) hist[i] = (uint32_t)(carry + e);
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tx;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* h, const uint32_t* idx, uint64_t n, uint64_t per, int shift,
+                                                      const uint32_t* hist, uint32_t G, uint64_t* h2, uint32_t* idx2) {
+    __shared__ uint32_t base[16];
+    __shared__ uint32_t wcnt[DD_WG / 64][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 16) base[tid] = hist[tid * G + blockIdx.x];
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j0 = b; j0 < e; j0 += DD_WG) {            // sub-tiles in input order keep the pass stable
+        const uint64_t j = j0 + tid;
+        const bool live = j < e;
+        const uint64_t hv = live ? h[j] : 0;
+        const uint32_t iv = live ? idx[j] : 0;
+        const uint32_t d = live ? (uint32_t)((hv >> shift) & 15u) : 16u;
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t dd = 0; dd < 16; ++dd) {
+            const uint64_t m = __ballot(d == dd);
+            if (d == dd) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wv][dd] = __popcll(m);
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t o = base[d] + rank;
+            for (int w = 0; w < wv; ++w) o += wcnt[w][d];
+            h2[o] = hv; idx2[o] = iv;
+        }
+        __syncthreads();
+        if (tid < 16) { uint32_t s = 0; for (int w = 0; w < DD_WG / 64; ++w) s += wcnt[w][tid]; base[tid] += s; }
+        __syncthreads();
+    }
+}
+__global__ void k_dd_mark(const KeyRec* keys, const uint64_t* h, const uint32_t* idx, uint64_t n, uint8_t* flags, DedupResult* res) {
+    uint32_t mine = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t hv = h[j];
+        const KeyRec me = keys[idx[j]];
+        bool dup = false;
+        for (uint64_t b = j; b-- > 0 && h[b] == hv;) if (key_eq(keys[idx[b]], me)) { dup = true; break; }    // earlier in the run = earlier in the input
+        flags[idx[j]] = dup ? 1 : 0;
+        mine += dup ? 1u : 0u;
+    }
+    if (mine) atomicAdd((unsigned long long*)&res->dups, (unsigned long long)mine);
+    if (blockIdx.x == 0 && threadIdx.x == 0) res->total = n;
+}
+size_t dedup_work_bytes(uint64_t n) {
+    const uint64_t G = 1024;
+    return (size_t)(n * (8 + 8 + 4 + 4) + 16 * G * 4 + 4096);
+}
+hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* work, size_t work_bytes, DedupResult* d_res, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(d_res, 0, sizeof(DedupResult), s);
+    if (e != hipSuccess || n == 0) return e;
+    if (work_bytes < dedup_work_bytes(n) || n >= (1ull << 32)) return hipErrorInvalidValue;
+    uint8_t* w = (uint8_t*)work;
+    uint64_t* hA = (uint64_t*)w; w += n * 8;
+    uint64_t* hB = (uint64_t*)w; w += n * 8;
+    uint32_t* iA = (uint32_t*)w; w += n * 4;
+    uint32_t* iB = (uint32_t*)w; w += n * 4;
+    uint32_t* hist = (uint32_t*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    uint32_t G = (uint32_t)((n + 8191) / 8192);
+    if (G > 1024) G = 1024;
+    if (G == 0) G = 1;
+    const uint64_t per = (n + G - 1) / G;
+    hipLaunchKernelGGL(k_dd_init, dim3(1024), dim3(256), 0, s, keys, n, hA, iA);
+    for (int p = 0; p < DD_PASSES; ++p) {
+        hipLaunchKernelGGL(k_dd_hist, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)hA, n, per, 4 * p, hist, G);
+        hipLaunchKernelGGL(k_dd_scan, dim3(1), dim3(NT), 0, s, hist, 16u * G);
+        hipLaunchKernelGGL(k_dd_scatter, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)hA, (const uint32_t*)iA, n, per, 4 * p, (const uint32_t*)hist, G, hB, iB);
+        uint64_t* th = hA; hA = hB; hB = th;
+        uint32_t* ti = iA; iA = iB; iB = ti;
+    }
+    hipLaunchKernelGGL(k_dd_mark, dim3(1024), dim3(256), 0, s, keys, (const uint64_t*)hA, (const uint32_t*)iA, n, flags, d_res);
+    return hipGetLastError();
+}
+
+// Extension A10: contact counts per (chrA, chrB) over the key list.  dense_of_slot maps name-table slots to
+// dense ids (built on the host from the table); counts is ndense x ndense.  Ids < 32 go through an LDS
+// histogram (the main chromosomes), the rest straight to global atomics.
+__global__ __launch_bounds__(256) void k_chrstat(const KeyRec* keys, uint64_t n, const uint16_t* dense_of_slot, uint32_t ndense, unsigned long long* counts) {
+    __shared__ uint32_t loc[32 * 32];
+    for (int k = threadIdx.x; k < 1024; k += 256) loc[k] = 0;
+    __syncthreads();
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k0 = keys[j].k0;
+        const uint32_t a = dense_of_slot[(k0 >> 45) & (kChrSlots - 1u)], b = dense_of_slot[(k0 >> 32) & (kChrSlots - 1u)];
+        if (a < 32u && b < 32u) atomicAdd(&loc[a * 32u + b], 1u);
+        else atomicAdd(&counts[(uint64_t)a * ndense + b], 1ull);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += 256) {
+        const uint32_t a = k >> 5, b = k & 31;
+        if (loc[k] && a < ndense && b < ndense) atomicAdd(&counts[(uint64_t)a * ndense + b], (unsigned long long)loc[k]);
+    }
+}
+hipError_t launch_chrstat(const KeyRec* keys, uint64_t n, const uint16_t* dense_of_slot, uint32_t ndense, unsigned long long* counts, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_chrstat, dim3(512), dim3(256), 0, s, keys, n, dense_of_slot, ndense, counts);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------
 // synthetic SAM: sizes, then bytes (offsets from an exclusive scan done between the two kernels)

@@ -11,7 +11,7 @@ enum { CFG_FAST = 0, CFG_SMALL = 1 };
 
 // totals of the blocks a context has finished, kept on the device so that resident blocks chain
 // without a host round trip
-struct DevRun { uint64_t groups, sc; };
+struct DevRun { uint64_t groups, sc, emitted; };
 
 // One output region's cursors, alone on a 128-byte line so that the per-tile atomics of different
 // regions never meet.  a: .pairs bytes (low 40 bits) | emitted lines (high 24); b: .sam bytes | self-circles.
@@ -28,7 +28,7 @@ struct KArgs {
     uint64_t* descB;            //                            pair_bytes | self-circles
     uint64_t* descC;            //                            sam_bytes
     uint32_t* ticket;
-    uint32_t* tile_groups;      // per tile: groups opened in it; k_finish turns it into the exclusive prefix
+    uint64_t* tile_groups;      // per tile: groups opened (low 32) | pairs emitted (high 32); k_finish_scan turns both into exclusive prefixes
     int32_t ordered;            // 1: outputs in input order (decoupled look-back); 0: one atomic range per tile
     TileLast* tile_last;
     uint32_t* defer_list;       // tiles the lean kernel left to the generic one
@@ -43,6 +43,9 @@ struct KArgs {
     uint64_t pairs_rcap, sam_rcap, sc_rcap;   // capacity of one region in out.pairs / out.sam / out.sc
     uint64_t* sc_list;          // resolved self-circle group indices of the whole run (drained by the host)
     uint64_t sc_list_cap;
+    uint64_t keys_rcap;         // extension: raw key records per region (out.keys), 0 = off
+    KeyRec* key_list;           // extension: the run's key records in input order
+    uint64_t key_list_cap;
     OutPtrs out;                // whole buffers; per-tile limits are derived from the region
     unsigned long long* stamps; // diagnostic builds only (MKT_STAMPS), else null
     int32_t debug_stop;         // diagnostic builds only: leave every tile after phase k (timing ladder; outputs are wrong)
@@ -54,6 +57,12 @@ hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s);
 uint32_t fast_tile_bytes();
 uint32_t finish_chunk_tiles();
 hipError_t launch_finish(const KArgs& a, hipStream_t s);
+
+// extensions (duplicate marking, per-chromosome counts) over the run's key list
+struct DedupResult { uint64_t total, dups; };
+hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* work, size_t work_bytes, DedupResult* d_res, hipStream_t s);
+size_t dedup_work_bytes(uint64_t n);
+hipError_t launch_chrstat(const KeyRec* keys, uint64_t n, const uint16_t* dense_of_slot, uint32_t ndense, unsigned long long* counts, hipStream_t s);
 
 hipError_t launch_synth_sizes(const SynParams& p, uint64_t first, uint64_t n, uint64_t* sizes, hipStream_t s);
 hipError_t launch_exscan(uint64_t* v, uint64_t n, uint64_t* total, hipStream_t s);

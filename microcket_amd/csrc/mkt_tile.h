@@ -100,7 +100,7 @@ struct TileState {
             uint16_t g_chrA_len[Cfg::LCAP], g_chrB_len[Cfg::LCAP];
             uint32_t g_plen[Cfg::LCAP], g_slen[Cfg::LCAP], g_last_end[Cfg::LCAP];
             uint32_t x_pair[Cfg::LCAP], x_sam[Cfg::LCAP];
-            uint16_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP];
+            uint16_t x_grp[Cfg::LCAP], x_sc[Cfg::LCAP], x_emit[Cfg::LCAP];
             uint16_t em_idx[Cfg::LCAP];  // emit ordinal -> first line of the emitting group
         } g;
     } u;
@@ -380,10 +380,64 @@ template <class Cfg> MKT_HD void ph_group(TileState<Cfg>& st, const TextView& tv
 }
 
 // ---- phase: account for / emit the group opened by line i ---------------------------------------
+// Slot of a chromosome name in the run's table (claims an empty slot with one 64-bit CAS; no payload is ever read
+// back on the device, so no fences are needed).  Two names are the same chromosome iff their 64-bit FNV-1a agree.
+#if defined(__HIP_DEVICE_COMPILE__)
+MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
+    const uint64_t h = fnv1a64(tv, off, len);
+    uint32_t s = (uint32_t)(h >> 17) & (kChrSlots - 1u);
+    for (uint32_t probe = 0; probe < kChrSlots; ++probe) {
+        unsigned long long cur = __hip_atomic_load(&tab->hash[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == 0ull) {
+            cur = atomicCAS(&tab->hash[s], 0ull, (unsigned long long)h);
+            if (cur == 0ull) {                         // claimed: leave the name for the host
+                const uint32_t m = len < kChrNameMax ? len : kChrNameMax;
+                for (uint32_t i = 0; i < m; ++i) tab->name[s][i] = tv.at(off + i);
+                tab->name[s][63] = (uint8_t)m;
+                if (len > kChrNameMax) atomicOr(err, (uint32_t)E_FIELD_RANGE);
+                return s;
+            }
+        }
+        if (cur == h) return s;
+        s = (s + 1u) & (kChrSlots - 1u);
+    }
+    atomicOr(err, (uint32_t)E_FIELD_RANGE);
+    return 0;
+}
+#else
+MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
+    const uint64_t h = fnv1a64(tv, off, len);
+    uint32_t s = (uint32_t)(h >> 17) & (kChrSlots - 1u);
+    for (uint32_t probe = 0; probe < kChrSlots; ++probe) {
+        if (tab->hash[s] == 0ull) {
+            tab->hash[s] = h;
+            const uint32_t m = len < kChrNameMax ? len : kChrNameMax;
+            for (uint32_t i = 0; i < m; ++i) tab->name[s][i] = tv.at(off + i);
+            tab->name[s][63] = (uint8_t)m;
+            if (len > kChrNameMax) *err |= E_FIELD_RANGE;
+            return s;
+        }
+        if (tab->hash[s] == h) return s;
+        s = (s + 1u) & (kChrSlots - 1u);
+    }
+    *err |= E_FIELD_RANGE;
+    return 0;
+}
+#endif
+MKT_HD KeyRec make_key(uint32_t slotA, uint32_t posA, uint32_t slotB, uint32_t posB, bool minusA, bool minusB, uint32_t tile, uint32_t ordinal) {
+    KeyRec k;
+    k.k0 = ((uint64_t)slotA << 45) | ((uint64_t)slotB << 32) | posA;
+    k.k1 = ((uint64_t)posB << 32) | ((uint64_t)(minusA ? 1u : 0u) << 31) | ((uint64_t)(minusB ? 1u : 0u) << 30);
+    k.ord = ((uint64_t)tile << 16) | ordinal;
+    return k;
+}
+
 struct OutPtrs {                        // *_cap: end of the range this tile may write (its output region)
     uint8_t* pairs; uint64_t pairs_cap;
     uint8_t* sam; uint64_t sam_cap;
     uint64_t* sc; uint64_t sc_cap;      // self-circle groups: (tile << 32 | ordinal in tile), resolved to global indices by k_finish
+    KeyRec* keys; uint64_t keys_cap;    // extension: raw key records of the block (null: extension off)
+    ChrTab* chr;
 };
 
 // slow .sam copy: surviving lines of [first line, last member end), each followed by '\n'
@@ -412,6 +466,15 @@ template <class Cfg> MKT_HD void ph_account(TileState<Cfg>& st, const TextView& 
         uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
         if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
         else lds_or(&st.err, E_SC_CAP);
+    }
+    if ((info & GI_EMIT) && out.keys) {
+        const auto& g = st.u.g;
+        const uint64_t k = (uint64_t)st.base.emitted + g.x_emit[i];
+        if (k < out.keys_cap) {
+            const uint32_t sa = chr_slot(out.chr, tv, g.g_chrA[i], g.g_chrA_len[i], &st.err);
+            const uint32_t sb = chr_slot(out.chr, tv, g.g_chrB[i], g.g_chrB_len[i], &st.err);
+            out.keys[k] = make_key(sa, g.g_posA[i], sb, g.g_posB[i], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i]);
+        } else lds_or(&st.err, E_SC_CAP);
     }
     if ((info & GI_EMIT) && P.write_sam && !(info & GI_CONTIG)) sam_copy_slow(st, tv, P, out, i);
 }

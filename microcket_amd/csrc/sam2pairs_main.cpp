@@ -9,6 +9,10 @@
 //   MKT_DEVICE       HIP device ordinal (default 0)
 //   MKT_BLOCK_MB     SAM megabytes per GPU pass (default 256)
 //   MKT_TILES        auto | fast | small
+//   MKT_EXT=1        extensions (never change stdout / .sam / .log): also writes
+//                      <prefix>.<mode>.chrstat     chrA \t chrB \t count   (reported pairs per chromosome pair)
+//                      <prefix>.<mode>.dedup.stat  Total / Uniq / Dup of the pairs-level duplicate marking
+//                      <prefix>.<mode>.dups        0-based ordinals (input order) of the reported pairs that are duplicates
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,6 +71,8 @@ int main(int argc, char* argv[]) {
     p.tiles = MKT_TILES_AUTO;
     if ((e = getenv("MKT_TILES"))) p.tiles = !strcmp(e, "small") ? MKT_TILES_SMALL : !strcmp(e, "fast") ? MKT_TILES_FAST : MKT_TILES_AUTO;
 
+    const bool ext = (e = getenv("MKT_EXT")) && e[0] == '1';
+    if (ext) p.extensions = MKT_EXT_KEYS;
     mkt_ctx* ctx = nullptr;
     int rc = mkt_create(&p, &ctx);
     if (rc != MKT_OK) {
@@ -103,6 +109,23 @@ int main(int argc, char* argv[]) {
     mkt_format_log(&st, log, sizeof log);
     flog << log;
     flog.close();
+    if (ext) {
+        uint64_t total = 0, dups = 0;
+        std::vector<uint8_t> flags((size_t)st.pairs + 1);
+        rc = mkt_ext_dedup(ctx, 1, &total, &dups, flags.data(), flags.size());
+        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
+        std::ofstream fd((base + ".dedup.stat").c_str());
+        fd << "Total\t" << total << "\nUniq\t" << (total - dups) << "\nDup\t" << dups << "\n";
+        std::ofstream fl((base + ".dups").c_str());
+        for (uint64_t k = 0; k < total; ++k) if (flags[k]) fl << k << "\n";
+        size_t len = 0;
+        mkt_ext_chrstat(ctx, 1, nullptr, 0, &len);
+        std::vector<char> txt(len + 1);
+        rc = mkt_ext_chrstat(ctx, 1, txt.data(), txt.size(), &len);
+        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
+        std::ofstream fc((base + ".chrstat").c_str());
+        fc.write(txt.data(), (std::streamsize)len);
+    }
     mkt_destroy(ctx);
     return 0;
 }

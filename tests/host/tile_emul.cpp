@@ -86,7 +86,7 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
     sam.assign((size_t)n + 4096, 0);
     const uint64_t sc_base = sc.size();
     sc.resize(sc_base + (size_t)n / 2 + 16, 0);
-    OutPtrs out{pairs.data(), pairs.size(), sam.data(), sam.size(), sc.data(), sc.size()};
+    OutPtrs out{pairs.data(), pairs.size(), sam.data(), sam.size(), sc.data(), sc.size(), nullptr, 0, nullptr};
     std::vector<uint32_t> tile_groups;
     std::unique_ptr<TileState<Cfg>> stp(new TileState<Cfg>);
     TileState<Cfg>& st = *stp;

@@ -1,0 +1,86 @@
+"""Extensions: pairs-level duplicate marking and per-chromosome contact counts.
+
+NOT part of the reference's sam2pairs: parity is UNPINNED by the reference.  The checker here is a direct Python
+restatement of the definition over the ORACLE's .pairs output (input order):
+  duplicate  = an earlier reported pair has the same (chr1, pos1, chr2, pos2, strand1, strand2);
+  chrstat    = count of reported pairs per (chr1, chr2)  ==  `cut -f2,4 | sort | uniq -c` of the oracle's stdout.
+Also checked: enabling the extensions changes nothing in stdout / .sam / .log."""
+import collections
+import os
+
+import pytest
+
+import microcket_amd as m
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(pairs_bytes):
+    seen = set()
+    flags = bytearray()
+    stat = collections.Counter()
+    for line in pairs_bytes.split(b"\n")[:-1]:
+        f = line.split(b"\t")
+        key = tuple(f[1:7])
+        flags.append(1 if key in seen else 0)
+        seen.add(key)
+        stat[(f[1], f[3])] += 1
+    txt = b"".join(a + b"\t" + b + b"\t" + str(c).encode() + b"\n" for (a, b), c in sorted(stat.items()))
+    return bytes(flags), txt
+
+
+def _dup_heavy(n_groups):
+    """name-grouped SAM with many exact duplicate contacts (PCR-duplicate like) and chr10/chr2/chrX names"""
+    rows = []
+    for g in range(n_groups):
+        k = g % 37 if g % 3 else g            # two thirds of the pairs repeat one of 37 contacts
+        c1 = ("chr1", "chr10", "chr2", "chrX")[k % 4]
+        c2 = ("chr1", "chr10", "chr2", "chrX")[(k // 4) % 4] if k % 5 == 0 else c1
+        p1, p2 = 10000 + 97 * k, 50000 + 131 * k
+        f1, f2 = (65, 145) if k % 2 else (81, 129)
+        rows.append(f"r{g}\t{f1}\t{c1}\t{p1}\t60\t50M\t=\t1\t0\t{'ACGT' * 25}\t{'F' * 100}\n")
+        rows.append(f"r{g}\t{f2}\t{c2}\t{p2}\t60\t50M\t=\t1\t0\t{'ACGT' * 25}\t{'F' * 100}\n")
+    rows.append("zz\t65\tchr1\t1\t60\t50M\t=\t1\t0\tA\tF\nzz\t129\tchr1\t5000\t60\t50M\t=\t1\t0\tA\tF\n")
+    return "".join(rows).encode()
+
+
+@pytest.mark.parametrize("ordered,tiles", [(False, m.TILES_FAST), (True, m.TILES_FAST), (False, m.TILES_SMALL)])
+def test_dedup_and_chrstat_vs_definition(ordered, tiles):
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    for text, mode in ((_dup_heavy(6000), "unc"), (util.synth("unc", 61, 8000), "unc"), (util.synth("flash", 62, 6000), "flash"),
+                       (util.synth("stress", 63, 9000), "unc")):
+        po, so, lo, st = util.oracle_run(text, mode, 4, 0.5, 10, True)
+        want_flags, want_stat = _expected(po)
+        with m.Context(mode, 0.5, 10, True, 4, device=0, block_bytes=1 << 18, tiles=tiles, ordered=ordered, extensions=m.EXT_KEYS) as c:
+            p, s, stats, log = c.run_bytes(text, chunk=1 << 20)
+            total, dups, flags = c.ext_dedup(True)
+            chrstat = c.ext_chrstat(True)
+        # the extension leaves the reference outputs alone
+        assert log == lo and util.canon(p) == util.canon(po) and util.canon(s) == util.canon(so)
+        assert total == len(want_flags) == st.pairs
+        assert flags == want_flags
+        assert dups == sum(want_flags)
+        assert chrstat == want_stat
+
+
+def test_executable_side_files(tmp_path):
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    text = _dup_heavy(3000)
+    rc, out, s, log, err = util.cli_run(m.exe_path(), text, "unc", 4, 0.5, 10, True, env={"MKT_EXT": "1", "MKT_BLOCK_MB": "1"})
+    assert rc == 0, err
+    po, so, lo, st = util.oracle_run(text, "unc", 4, 0.5, 10, True)
+    assert log == lo and util.canon(out) == util.canon(po)
+    # side files live next to the log (util.cli_run uses a temp dir; run again in tmp_path to read them)
+    import subprocess
+    inp = tmp_path / "in.sam"
+    inp.write_bytes(text)
+    e = dict(os.environ, MKT_EXT="1")
+    p = subprocess.run([m.exe_path(), str(inp), "unc", str(tmp_path / "o"), "4", "0.5", "10", "no"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    assert p.returncode == 0, p.stderr
+    want_flags, want_stat = _expected(po)
+    assert (tmp_path / "o.unc.chrstat").read_bytes() == want_stat
+    assert (tmp_path / "o.unc.dedup.stat").read_text() == f"Total\t{len(want_flags)}\nUniq\t{len(want_flags) - sum(want_flags)}\nDup\t{sum(want_flags)}\n"
+    assert (tmp_path / "o.unc.dups").read_text() == "".join(f"{k}\n" for k, f in enumerate(want_flags) if f)
