@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
+    ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -99,8 +101,13 @@ def main():
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if args.same_gpu:
+            local = 0
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend="gloo")
     else:
         try:
             import torch  # noqa: F811  (only for torch.cuda.synchronize around the timed region)
@@ -113,9 +120,12 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    tdev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
+
     def dev_sync():
-        if torch is not None and torch.cuda.is_available():
+        if torch is not None and tdev == "cuda" and torch.cuda.is_available():
             torch.cuda.synchronize()
+        ctx.sync()
 
     profile = 0 if args.mode == "unc" else 1
     seed = 20260104 + 1  # seeds 20260104 + config index
@@ -144,7 +154,7 @@ def main():
     dev_sync(); barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     tmg = ctx.timing()
@@ -162,7 +172,7 @@ def main():
         last_nonempty = max(i for i, g in enumerate(gl) if g > 0)
         st = ctx.finish(drop_last=(rank == last_nonempty), group_offset=offset, total_groups=total)
         cnt = torch.tensor([st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes],
-                           dtype=torch.int64, device="cuda")
+                           dtype=torch.int64, device=tdev)
         dist.all_reduce(cnt)
         counters = [int(x) for x in cnt.tolist()]
     else:
