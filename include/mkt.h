@@ -159,6 +159,16 @@ void mkt_dataset_destroy(mkt_dataset* ds);
  * same key.  flags (may be NULL) receives one byte per reported pair in input order (1 = duplicate).
  * drop_last as in mkt_finish.  Requires MKT_EXT_KEYS. */
 int mkt_ext_dedup(mkt_ctx* ctx, int drop_last, uint64_t* total, uint64_t* dups, uint8_t* flags, size_t flags_cap);
+/* Sharded duplicate marking (one context per GPU): the key space is exchanged by the caller (RCCL all-gather through
+ * torch.distributed in microcket_amd/shard.py) and marked with the same kernels.
+ *   mkt_ext_chr_names   the context's chromosome-name table as "slot\tname\n" lines (slots are per context);
+ *   mkt_ext_keys_fetch  the context's key records (24 bytes each: k0, k1, ordinal; see mkt_core.h KeyRec) in input order;
+ *   mkt_ext_dedup_keys  duplicate flags for ANY key array in input order (e.g. the concatenation of all shards with
+ *                       chromosome slots rewritten to ids that are the same on every rank). */
+int mkt_ext_chr_names(mkt_ctx* ctx, char* out, size_t cap, size_t* len);
+int mkt_ext_keys_fetch(mkt_ctx* ctx, int drop_last, void* keys, size_t cap_bytes, uint64_t* n);
+int mkt_ext_dedup_keys(mkt_ctx* ctx, const void* keys, uint64_t n, uint8_t* flags, uint64_t* dups);
+
 /* Per-chromosome contact counts of the reported pairs: lines "chrA\tchrB\tcount\n" sorted bytewise by (chrA, chrB). */
 int mkt_ext_chrstat(mkt_ctx* ctx, int drop_last, char* out, size_t cap, size_t* len);
 

@@ -11,7 +11,7 @@ EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
     "mkt_submit", "mkt_drain", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
-    "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
+    "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
 ]
 
 
@@ -90,6 +90,9 @@ def load_library():
     L.mkt_reset.argtypes = [C.c_void_p]
     L.mkt_ext_dedup.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_size_t]
     L.mkt_ext_chrstat.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mkt_ext_chr_names.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.mkt_ext_keys_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.mkt_ext_dedup_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.mkt_group_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     _lib = L
     return L
@@ -210,6 +213,40 @@ class Context:
         buf = C.create_string_buffer(tot.value)
         self._chk(self.L.mkt_ext_dedup(self.h, 1 if drop_last else 0, C.byref(tot), C.byref(dup), buf, tot.value), "mkt_ext_dedup")
         return tot.value, dup.value, buf.raw[:tot.value]
+
+    def ext_chr_names(self):
+        """{slot: name} of this context's chromosome-name table"""
+        n = C.c_size_t()
+        self._chk(self.L.mkt_ext_chr_names(self.h, None, 0, C.byref(n)), "mkt_ext_chr_names")
+        buf = C.create_string_buffer(max(n.value, 1))
+        self._chk(self.L.mkt_ext_chr_names(self.h, buf, n.value, C.byref(n)), "mkt_ext_chr_names")
+        out = {}
+        for line in buf.raw[:n.value].split(b"\n"):
+            if line:
+                s, name = line.split(b"\t", 1)
+                out[int(s)] = name
+        return out
+
+    def ext_keys_fetch(self, drop_last=True):
+        """key records as a numpy uint64 array of shape (n, 3): k0, k1, ordinal (input order)"""
+        import numpy as np
+        n = C.c_uint64()
+        self._chk(self.L.mkt_ext_keys_fetch(self.h, 1 if drop_last else 0, None, 0, C.byref(n)), "mkt_ext_keys_fetch")
+        arr = np.zeros((n.value, 3), dtype=np.uint64)
+        if n.value:
+            self._chk(self.L.mkt_ext_keys_fetch(self.h, 1 if drop_last else 0, arr.ctypes.data_as(C.c_void_p), arr.nbytes, C.byref(n)), "mkt_ext_keys_fetch")
+        return arr
+
+    def ext_dedup_keys(self, keys):
+        """duplicate flags (numpy uint8) for a (n, 3) uint64 key array in input order; runs on this context's GPU"""
+        import numpy as np
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        n = keys.shape[0]
+        flags = np.zeros(n, dtype=np.uint8)
+        dups = C.c_uint64()
+        if n:
+            self._chk(self.L.mkt_ext_dedup_keys(self.h, keys.ctypes.data_as(C.c_void_p), n, flags.ctypes.data_as(C.c_void_p), C.byref(dups)), "mkt_ext_dedup_keys")
+        return flags, dups.value
 
     def ext_chrstat(self, drop_last=True):
         n = C.c_size_t()

@@ -563,6 +563,60 @@ int mkt_ext_dedup(mkt_ctx* c, int drop_last, uint64_t* total, uint64_t* dups, ui
     if (dups) *dups = r.dups;
     return MKT_OK;
 }
+int mkt_ext_chr_names(mkt_ctx* c, char* out, size_t cap, size_t* len) {
+    if (!c || !len) return MKT_E_ARG;
+    if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    *len = 0;
+    if (!c->d_chr) return MKT_OK;
+    std::vector<unsigned long long> hh(kChrSlots);
+    std::vector<uint8_t> names((size_t)kChrSlots * 64);
+    HIPCHK(c, hipMemcpy(hh.data(), c->d_chr->hash, kChrSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(names.data(), c->d_chr->name, names.size(), hipMemcpyDeviceToHost));
+    std::string txt;
+    char num[16];
+    for (uint32_t s2 = 0; s2 < kChrSlots; ++s2) if (hh[s2]) {
+        snprintf(num, sizeof num, "%u", s2);
+        txt += num; txt += '\t'; txt.append((const char*)&names[(size_t)s2 * 64], names[(size_t)s2 * 64 + 63]); txt += '\n';
+    }
+    *len = txt.size();
+    if (out) { if (cap < txt.size()) return fail(c, MKT_E_ARG, "buffer too small (%zu needed)", txt.size()); memcpy(out, txt.data(), txt.size()); }
+    return MKT_OK;
+}
+int mkt_ext_keys_fetch(mkt_ctx* c, int drop_last, void* keys, size_t cap_bytes, uint64_t* n) {
+    if (!c || !n) return MKT_E_ARG;
+    if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    *n = ext_key_count(c, drop_last);
+    if (keys && *n) {
+        if (cap_bytes < *n * sizeof(KeyRec)) return fail(c, MKT_E_ARG, "key buffer too small (%llu bytes needed)", (unsigned long long)(*n * sizeof(KeyRec)));
+        HIPCHK(c, hipMemcpy(keys, c->d_key_list, (size_t)*n * sizeof(KeyRec), hipMemcpyDeviceToHost));
+    }
+    return MKT_OK;
+}
+int mkt_ext_dedup_keys(mkt_ctx* c, const void* keys, uint64_t n, uint8_t* flags, uint64_t* dups) {
+    if (!c || (n && (!keys || !flags))) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    if (dups) *dups = 0;
+    if (n == 0) return MKT_OK;
+    KeyRec* d_keys = nullptr; uint8_t* d_flags = nullptr; void* d_work = nullptr; DedupResult* d_res = nullptr;
+    const size_t wb = dedup_work_bytes(n);
+    HIPCHK(c, hipMalloc((void**)&d_keys, (size_t)n * sizeof(KeyRec)));
+    HIPCHK(c, hipMalloc((void**)&d_flags, n));
+    HIPCHK(c, hipMalloc(&d_work, wb));
+    HIPCHK(c, hipMalloc((void**)&d_res, sizeof(DedupResult)));
+    HIPCHK(c, hipMemcpyAsync(d_keys, keys, (size_t)n * sizeof(KeyRec), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_dedup(d_keys, n, d_flags, d_work, wb, d_res, c->stream));
+    DedupResult r;
+    HIPCHK(c, hipMemcpyAsync(&r, d_res, sizeof r, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_keys); (void)hipFree(d_flags); (void)hipFree(d_work); (void)hipFree(d_res);
+    if (dups) *dups = r.dups;
+    return MKT_OK;
+}
 int mkt_ext_chrstat(mkt_ctx* c, int drop_last, char* out, size_t cap, size_t* len) {
     if (!c || !len) return MKT_E_ARG;
     if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");

@@ -65,3 +65,60 @@ def finish_sharded(engine, rank, world, all_gather_int, all_reduce_sum):
 
 def format_log(counters):
     return "".join(f"{k}\t{counters[k]}\n" for k in COUNTERS).encode()
+
+
+def dedup_sharded(ctx, rank, world, drop_last, all_gather_obj, all_gather_keys):
+    """Pairs-level duplicate marking across shards (extension): an all-gather of the dedup key space.
+
+    Shards are contiguous ranges of the input in rank order, so the concatenation of the ranks' key lists IS the
+    input order.  Chromosome slots are per context: the name tables are gathered first and every slot is rewritten to
+    the rank of its name in the sorted union, which is the same on every rank.
+      all_gather_obj(x)   -> list of every rank's small Python object (name tables)
+      all_gather_keys(a)  -> list of every rank's (n_r, 3) uint64 array (RCCL all_gather of padded device tensors in
+                             bench / production; plain lists in the single-GPU tests)
+    Returns (flags of this rank's reported pairs, duplicates on this rank, total duplicates)."""
+    import numpy as np
+    names = ctx.ext_chr_names()
+    union = sorted(set().union(*[set(t.values()) for t in all_gather_obj(names)]))
+    gid = {nm: i for i, nm in enumerate(union)}
+    lut = np.zeros(8192, dtype=np.uint64)
+    for slot, nm in names.items():
+        lut[slot] = gid[nm]
+    keys = ctx.ext_keys_fetch(drop_last)
+    if keys.shape[0]:
+        k0 = keys[:, 0]
+        a = lut[((k0 >> np.uint64(45)) & np.uint64(8191)).astype(np.int64)]
+        b = lut[((k0 >> np.uint64(32)) & np.uint64(8191)).astype(np.int64)]
+        keys[:, 0] = (a << np.uint64(45)) | (b << np.uint64(32)) | (k0 & np.uint64(0xFFFFFFFF))
+    parts = all_gather_keys(keys)
+    start = sum(p.shape[0] for p in parts[:rank])
+    allk = np.concatenate(parts, axis=0) if parts else keys
+    flags, total_dups = ctx.ext_dedup_keys(allk)
+    mine = flags[start:start + keys.shape[0]]
+    return mine, int(mine.sum()), int(total_dups)
+
+
+def torch_gatherers(dist, torch, device, world):
+    """(all_gather_obj, all_gather_keys) over torch.distributed for dedup_sharded: the key arrays travel as padded int64
+    tensors on `device` (backend nccl = RCCL over xGMI when device is a GPU; gloo with device "cpu" in the CPU tests)."""
+    import numpy as np
+
+    def ag_obj(x):
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    def ag_keys(k):
+        n = torch.tensor([k.shape[0]], dtype=torch.int64, device=device)
+        ns = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(ns, n)
+        ns = [int(t.item()) for t in ns]
+        mx = max(max(ns), 1)
+        pad = np.zeros((mx, 3), dtype=np.int64)
+        pad[:k.shape[0]] = k.view(np.int64)
+        t = torch.from_numpy(pad).to(device)
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [o[:ns[r]].cpu().numpy().view(np.uint64).reshape(ns[r], 3) for r, o in enumerate(outs)]
+
+    return ag_obj, ag_keys

@@ -85,3 +85,25 @@ def test_more_ranks_than_groups():
     cuts = shard.cut_points(text, 8)
     assert cuts[-1] == len(text)
     assert b"".join(text[cuts[i]:cuts[i + 1]] for i in range(8)) == text
+
+
+def _gather_worker(rank, world, port, outdir):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ag_obj, ag_keys = shard.torch_gatherers(dist, torch, "cpu", world)
+    k = (np.arange((rank + 1) * 5 * 3, dtype=np.uint64).reshape(-1, 3) + np.uint64(rank) * np.uint64(1 << 60))
+    parts = ag_keys(k)
+    objs = ag_obj({rank: b"chr%d" % rank})
+    ok = len(parts) == world and all(p.shape == ((r + 1) * 5, 3) and int(p[0, 0] >> np.uint64(60)) == r for r, p in enumerate(parts))
+    ok = ok and objs == [{r: b"chr%d" % r} for r in range(world)]
+    open(os.path.join(outdir, f"ok.{rank}"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_key_space_gatherers_over_gloo(tmp_path):
+    """The exchange primitives of the sharded duplicate marking (shard.torch_gatherers), world_size 2 on CPU."""
+    mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok.0").read_text() == "1" and (tmp_path / "ok.1").read_text() == "1"

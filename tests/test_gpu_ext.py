@@ -84,3 +84,46 @@ def test_executable_side_files(tmp_path):
     assert (tmp_path / "o.unc.chrstat").read_bytes() == want_stat
     assert (tmp_path / "o.unc.dedup.stat").read_text() == f"Total\t{len(want_flags)}\nUniq\t{len(want_flags) - sum(want_flags)}\nDup\t{sum(want_flags)}\n"
     assert (tmp_path / "o.unc.dups").read_text() == "".join(f"{k}\n" for k, f in enumerate(want_flags) if f)
+
+
+def test_sharded_dedup_equals_single_context():
+    """Two contexts = two shards on one GPU; the key-space exchange is emulated with Python lists (bench / production
+    pass RCCL all-gathers).  Flags must equal the single-context result; chromosome slots differ between the contexts
+    (insertion / probing order), which the name-table exchange has to undo."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    from microcket_amd import shard
+    text = _dup_heavy(5000) + util.synth("unc", 71, 3000)
+    # make sure the final shard holds the input's last group, as in a real run
+    with m.Context("unc", 0.5, 10, False, 4, device=0, extensions=m.EXT_KEYS, ordered=True) as c:
+        c.run_bytes(text)
+        total, dups, want = c.ext_dedup(True)
+    cuts = shard.cut_points(text, 2)
+    ctxs = [m.Context("unc", 0.5, 10, False, 4, device=0, extensions=m.EXT_KEYS) for _ in range(2)]
+    # feed the second shard first into its context so the two name tables fill in different orders
+    ctxs[1].submit(text[cuts[1]:cuts[2]], last=True)
+    ctxs[0].submit(text[cuts[0]:cuts[1]], last=True)
+    counts = [c.group_count() for c in ctxs]
+    for r, c in enumerate(ctxs):
+        c.finish(drop_last=(r == 1), group_offset=sum(counts[:r]), total_groups=sum(counts))
+    names = [c.ext_chr_names() for c in ctxs]
+    keys = []
+    # first "gather": every rank's remapped keys (dedup_sharded remaps before gathering; emulate the two-step exchange)
+    import numpy as np
+    got = []
+    stash = {}
+
+    def run(rank):
+        def ag_obj(x):
+            return names
+        def ag_keys(k):
+            stash[rank] = k
+            return [stash.get(0, np.zeros((0, 3), np.uint64)), stash.get(1, np.zeros((0, 3), np.uint64))]
+        return shard.dedup_sharded(ctxs[rank], rank, 2, rank == 1, ag_obj, ag_keys)
+    run(0)                       # fills stash[0] (its own result is incomplete: rank 1 not gathered yet)
+    f1, d1, tot1 = run(1)        # both shards present
+    f0, d0, tot0 = run(0)
+    for c in ctxs:
+        c.close()
+    assert bytes(f0) + bytes(f1) == want
+    assert d0 + d1 == dups == tot0 == tot1
