@@ -56,6 +56,8 @@ struct FastState {
             uint64_t l_litA[Cfg::GCAP][2], l_litB[Cfg::GCAP][2];   // "<posA>\t" and "<posB>\t<sA>\t<sB>\n", little-endian bytes
         } g;
     } u;
+    // one bit per line of the window (ballots of the parse / start phases)
+    uint64_t m_surv[4], m_eqp[4], m_r1[4], m_r2[4], m_start[4], m_emit[4];
     uint32_t NL, first_idx, end_idx, abn, last_line_end, nslot;
     uint32_t cnt[C_COUNT];
     TileSums sums, base;                  // base: ABSOLUTE positions in OutPtrs::pairs / sam / sc
@@ -79,6 +81,7 @@ template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const u
 }
 template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
     st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown; st.nslot = 0;
+    for (int k = 0; k < 4; ++k) st.m_emit[k] = 0;
     st.region_pair0 = 0; st.region_sam0 = 0; st.region_id = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
 }
@@ -144,24 +147,72 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     st.bits[i] = b;
 }
 
-// ---- does surviving line i open a group? ---------------------------------------------------------
-template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextView& tv, const TileGeom& G, uint32_t i) {
-    // usual case: the line before survives, and "same QNAME token as the line before" was settled while parsing
-    if (i > 0 && (st.bits[i - 1] & LB_SURVIVE)) return !(st.bits[i] & LB_EQPREV);
-    bool chain = true;
-    uint32_t j = i;
-    for (;;) {
-        if (j == 0) {
-            if (G.w0 == 0) return true;               // first surviving line of the block
-            st.abn = 1;                               // the previous surviving line is before the window
-            return false;
-        }
-        chain = chain && (st.bits[j] & LB_EQPREV);
-        --j;
-        if (st.bits[j] & LB_SURVIVE) break;
+// ---- line masks ------------------------------------------------------------------------------------
+MKT_HD bool mask_bit(const uint64_t* m, uint32_t i) { return (m[i >> 6] >> (i & 63u)) & 1ull; }
+MKT_HD uint64_t mask_range(uint32_t w, uint32_t lo, uint32_t hi) {        // bits of word w inside [lo, hi)
+    const uint32_t b = w << 6;
+    if (hi <= b || lo >= b + 64u) return 0ull;
+    const uint32_t l = lo > b ? lo - b : 0u, h = hi < b + 64u ? hi - b : 64u;
+    const uint64_t up = h >= 64u ? ~0ull : ((1ull << h) - 1ull);
+    return up & ~((1ull << l) - 1ull);
+}
+MKT_HD uint32_t clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clzll((long long)x);
+#else
+    return (uint32_t)__builtin_clzll(x);
+#endif
+}
+MKT_HD uint32_t popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+// 64 lines of a mask as one word: bit k = line start + k (lines past the table read as 0)
+MKT_HD uint64_t mask_win(const uint64_t* m, uint32_t start) {
+    const uint32_t w = start >> 6, s = start & 63u;
+    uint64_t x = m[w] >> s;
+    if (s && w < 3u) x |= m[w + 1u] << (64u - s);
+    return x;
+}
+// the same ending at line i: bit 63 = line i, bit 62 = line i - 1, ...
+MKT_HD uint64_t mask_win_back(const uint64_t* m, uint32_t i) {
+    return i >= 63u ? mask_win(m, i - 63u) : (m[0] << (63u - i));
+}
+MKT_HD uint32_t mask_next(const uint64_t* m, uint32_t from, uint32_t limit) {   // lowest set bit in [from, limit), or limit
+    for (uint32_t w = from >> 6; (w << 6) < limit && w < 4u; ++w) {
+        const uint64_t x = m[w] & mask_range(w, from, limit);
+        if (x) return (w << 6) + ctz64(x);
     }
-    if (chain) return false;
-    return !text_eq<true>(tv, G.w0 + st.off16[i] + st.qn_off[i], st.qn_len[i], G.w0 + st.off16[j] + st.qn_off[j], st.qn_len[j]);
+    return limit;
+}
+// host side of what the kernel does with __ballot after fast_parse
+template <class Cfg> MKT_HD void fast_build_masks(FastState<Cfg>& st) {
+    for (int k = 0; k < 4; ++k) st.m_surv[k] = st.m_eqp[k] = st.m_r1[k] = st.m_r2[k] = 0;
+    for (uint32_t i = 0; i < st.NL; ++i) {
+        const uint64_t bit = 1ull << (i & 63u);
+        if (st.bits[i] & LB_SURVIVE) st.m_surv[i >> 6] |= bit;
+        if (st.bits[i] & LB_EQPREV) st.m_eqp[i >> 6] |= bit;
+        if ((st.bits[i] & LB_SURVIVE) && (st.flag[i] & 64u)) st.m_r1[i >> 6] |= bit;
+        if ((st.bits[i] & LB_SURVIVE) && !(st.flag[i] & 64u) && (st.flag[i] & 128u)) st.m_r2[i >> 6] |= bit;
+    }
+}
+
+// ---- does surviving line i open a group?  (its QNAME differs from the previous SURVIVING line's) --------
+template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextView& tv, const TileGeom& G, uint32_t i) {
+    const uint64_t sv = mask_win_back(st.m_surv, i) & ~(1ull << 63);      // the 63 lines before line i
+    if (!sv) {
+        if (G.w0 == 0 && i < 64u) return true;        // first surviving line of the block
+        st.abn = 1;                                   // the previous surviving line is before the window (or > 63 lines back)
+        return false;
+    }
+    const uint32_t d = clz64(sv), p = i - d;          // previous surviving line
+    // every line in (p, i] has the QNAME token of the line before it  =>  equal by transitivity
+    if (((~mask_win_back(st.m_eqp, i)) >> (64u - d)) == 0ull) return false;
+    if (d == 1u) return true;                         // adjacent surviving lines with different tokens
+    return !text_eq<true>(tv, G.w0 + st.off16[i] + st.qn_off[i], st.qn_len[i], G.w0 + st.off16[p] + st.qn_off[p], st.qn_len[p]);
 }
 
 template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, const TileGeom& G, uint32_t idx) {
@@ -174,37 +225,48 @@ template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, const TileGeo
     return s;
 }
 
-// ---- walk + classify the group opened by line i --------------------------------------------------
+// ---- the group opened by line i: extent, members and record slots from the masks; classification --------
 template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
     auto& g = st.u.g;
     g.g_info[i] = 0; g.g_plen[i] = 0; g.g_slen[i] = 0;
-    if (!(st.bits[i] & LB_SURVIVE) || !fast_is_start(st, tv, G, i)) return;
+    if (!mask_bit(st.m_start, i)) return;
+#if defined(MKT_DIAG_NOWALK)
+    g.g_info[i] = GI_START; return;
+#endif
     const uint32_t NLe = fast_nle(st);
-    uint32_t nmem = 0, n1 = 0, n2 = 0, sa = 0xFFFFu, sb = 0xFFFFu, sc = 0xFFFFu, sd = 0xFFFFu, sam_bytes = 0;
-    uint32_t j = i;
-    bool closed = false;
-    while (j < NLe) {
-        const uint8_t b = st.bits[j];
-        if (b & LB_SURVIVE) {
-            if (j > i) {
-                bool same;
-                if ((b & LB_EQPREV) && (st.bits[j - 1] & LB_SURVIVE)) same = true;
-                else same = !fast_is_start(st, tv, G, j);
-                if (!same) { closed = true; break; }
-            }
-            const uint32_t f = st.flag[j];
-            if (P.mode == MODE_FLASH) { if (nmem == 0) sa = j; else if (nmem == 1) sb = j; }
-            else if (f & 64u) { if (n1 == 0) sa = j; else if (n1 == 1) sb = j; ++n1; }
-            else if (f & 128u) { if (n2 == 0) sc = j; else if (n2 == 1) sd = j; ++n2; }
-            ++nmem;
-            const uint32_t e = fast_line_end(st, G, j);
-            if (e == kUnknown || e >= tv.n) st.abn = 1;           // line end beyond the window / no final newline
-            else sam_bytes += e + 1u - (G.w0 + st.off16[j]);
-        }
-        ++j;
+    // lines i .. i+63 as one word per mask; the group ends before the next start bit
+    const uint64_t nx = mask_win(st.m_start, i) >> 1;
+    uint32_t len;
+    if (nx) len = ctz64(nx) + 1u;
+    else {
+        len = NLe - i;
+        if (G.w1 < tv.n || len > 64u) { st.abn = 1; return; }        // the group may continue past the window
     }
-    if (!closed && G.w1 < tv.n) { st.abn = 1; return; }           // the group may continue past the window
+    const uint64_t in = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
+    const uint64_t mem = mask_win(st.m_surv, i) & in;                 // bit 0 (line i) is set
+    const uint32_t nmem = popc64(mem);
+    uint32_t n1 = 0, n2 = 0, sa, sb = 0xFFFFu, sc = 0xFFFFu, sd = 0xFFFFu;
+    if (P.mode == MODE_FLASH) {
+        sa = i;
+        const uint64_t r = mem & (mem - 1ull);
+        if (r) sb = i + ctz64(r);
+    } else {
+        uint64_t r = mask_win(st.m_r1, i) & in;
+        n1 = popc64(r);
+        sa = r ? i + ctz64(r) : 0xFFFFu; r &= r - 1ull;
+        if (r) sb = i + ctz64(r);
+        r = mask_win(st.m_r2, i) & in;
+        n2 = popc64(r);
+        if (r) { sc = i + ctz64(r); r &= r - 1ull; }
+        if (r) sd = i + ctz64(r);
+    }
+    // a member whose line end is not known (last line of the table) or that lacks its final newline: generic kernel
+    if (i + 64u - clz64(mem) == st.NL && (st.last_line_end == kUnknown || st.last_line_end >= tv.n)) st.abn = 1;
     Verdict v;
+#if defined(MKT_DIAG_NOCLASSIFY)
+    v = verdict_none(C_TRANS); v.emit = nmem >= 2; v.chrA_off = v.chrB_off = G.w0 + st.off16[i] + st.rn_off[i]; v.chrA_len = v.chrB_len = st.rn_len[i]; v.posA = st.pos[i]; v.posB = st.pos[i] + nmem;
+    if (false)
+#endif
     {
         Seg a = sa != 0xFFFFu ? fast_seg(st, G, sa) : seg_zero();
         Seg b = sb != 0xFFFFu ? fast_seg(st, G, sb) : seg_zero();
@@ -229,6 +291,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
         const uint32_t e0 = ql + 1u, e1 = e0 + v.chrA_len + 1u, e2 = e1 + dA + 1u, e3 = e2 + v.chrB_len + 1u;
         g.l_e0[slot] = (uint16_t)e0; g.l_e1[slot] = (uint16_t)e1; g.l_e2[slot] = (uint16_t)e2; g.l_e3[slot] = (uint16_t)e3;
         g.l_posA[slot] = v.posA; g.l_posB[slot] = v.posB;
+#if !defined(MKT_DIAG_NOLIT)
         {   // literals "<posA>\t" and "<posB>\t<sA>\t<sB>\n", text order = little-endian byte order
             uint64_t w0, w1;
             dec_lit(v.posA, dA, (uint64_t)'\t', w0, w1);
@@ -237,10 +300,12 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
             dec_lit(v.posB, dB, tail, w0, w1);
             g.l_litB[slot][0] = w0; g.l_litB[slot][1] = w1;
         }
+#endif
         g.g_plen[i] = (uint16_t)(e3 + dB + 5u);
-        if (P.write_sam) {
-            g.g_slen[i] = sam_bytes;
-            for (uint32_t k = i; k < j; ++k) if (st.bits[k] & LB_SURVIVE) st.bits[k] |= LB_EMIT;    // members (byte-wide RMW, other bits untouched)
+        if (P.write_sam) {                             // the group's surviving lines go to the .sam
+            const uint32_t w = i >> 6, sh = i & 63u;
+            lds_or64(&st.m_emit[w], mem << sh);
+            if (sh && (mem >> (64u - sh)) && w < 3u) lds_or64(&st.m_emit[w + 1u], mem >> (64u - sh));
         }
     }
     g.g_info[i] = info;
@@ -248,7 +313,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
 
 // bytes line i contributes to the tile's .sam output
 template <class Cfg> MKT_HD uint32_t fast_line_sam(const FastState<Cfg>& st, const TileGeom& G, uint32_t i) {
-    if (!(st.bits[i] & LB_EMIT)) return 0u;
+    if (!mask_bit(st.m_emit, i)) return 0u;
     return fast_line_end(st, G, i) + 1u - (G.w0 + st.off16[i]);
 }
 
@@ -278,14 +343,21 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
         } else st.abn = E_SC_CAP << 8;
     }
 }
-template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, TileLast* tl, uint32_t i) {
+template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, const TileGeom& G, TileLast* tl, uint32_t i) {
     const auto& g = st.u.g;
     const uint32_t info = g.g_info[i];
     if (!(info & GI_START)) return;
     if ((uint32_t)g.x_grp[i] + 1u != st.sums.groups) return;
     tl->counter = info & GI_COUNTER;
     tl->pair_bytes = g.g_plen[i];
-    tl->sam_bytes = g.g_slen[i];
+    {   // .sam bytes of this group: its surviving lines up to the next group's first line
+        uint32_t sb = 0;
+        if (mask_bit(st.m_emit, i)) {
+            const uint32_t end = mask_next(st.m_start, i + 1u, fast_nle(st));
+            for (uint32_t k = i; k < end; ++k) if (mask_bit(st.m_surv, k)) sb += fast_line_end(st, G, k) + 1u - (G.w0 + st.off16[k]);
+        }
+        tl->sam_bytes = sb;
+    }
     tl->pair_off = st.base.pair_bytes - st.region_pair0 + g.x_pair[i];
     tl->sam_off = (uint32_t)(st.base.sam_bytes - st.region_sam0 + g.x_sam[i]);
     tl->region = st.region_id; tl->pad = 0;

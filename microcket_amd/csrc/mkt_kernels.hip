@@ -14,6 +14,9 @@
 #include "mkt_launch.h"
 
 // tile geometry of the fast configuration (the lean and the generic kernel must agree on TILE)
+#ifndef MKT_RR
+#define MKT_RR 4          // waves that share the group phase of a tile (lines dealt round-robin)
+#endif
 #ifndef MKT_LEAN_TILE
 #define MKT_LEAN_TILE 16384
 #define MKT_LEAN_HB 2048
@@ -485,15 +488,32 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         __syncthreads();
 
         // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
-        const uint32_t rr_id = ((uint32_t)tid & 63u) * (NT / 64) + ((uint32_t)tid >> 6);
-        for (uint32_t i = tid; i < NL; i += NT) fast_parse(st, tv, P, G, i);
+        const uint32_t rr_id = ((uint32_t)tid >> 6) < (uint32_t)MKT_RR ? ((uint32_t)tid & 63u) * MKT_RR + ((uint32_t)tid >> 6) : 0xFFFFFFu;
+        {   // one lane per line (LCAP < NT); the line masks are the waves' ballots
+            static_assert(Cfg::LCAP <= NT, "one parse lane per line");
+            const uint32_t i = (uint32_t)tid;
+            uint32_t lb = 0, fl = 0;
+            if (i < NL) { fast_parse(st, tv, P, G, i); lb = st.bits[i]; fl = st.flag[i]; }
+            const bool sv = (lb & LB_SURVIVE) != 0;
+            const uint64_t b_s = __ballot(sv), b_e = __ballot((lb & LB_EQPREV) != 0);
+            const uint64_t b_1 = __ballot(sv && (fl & 64u)), b_2 = __ballot(sv && !(fl & 64u) && (fl & 128u));
+            if ((tid & 63) == 0) { const int w = tid >> 6; st.m_surv[w] = b_s; st.m_eqp[w] = b_e; st.m_r1[w] = b_1; st.m_r2[w] = b_2; }
+        }
         __syncthreads();
         STAMP(3);
         STOP_AFTER(3)
         const uint32_t NLe = fast_nle(st);
         const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe;
         const uint32_t end_idx = st.end_idx < NLe ? st.end_idx : NLe;
-        if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += NT) fast_group(st, tv, P, G, i);
+        {   // which surviving lines open a group
+            const uint32_t i = (uint32_t)tid;
+            bool s0 = false;
+            if (!st.abn && i >= first_idx && i < NLe && mask_bit(st.m_surv, i)) s0 = fast_is_start(st, tv, G, i);
+            const uint64_t b = __ballot(s0);
+            if ((tid & 63) == 0) st.m_start[tid >> 6] = b;
+        }
+        __syncthreads();
+        if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * MKT_RR) fast_group(st, tv, P, G, i);
         __syncthreads();
         STAMP(4);
         STOP_AFTER(4)
@@ -553,7 +573,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         // ---- emit ----------------------------------------------------------------------------------
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
             fast_account(st, s_out, t, i);
-            fast_last(st, &a.tile_last[t], i);
+            fast_last(st, G, &a.tile_last[t], i);
         }
         {
             const uint32_t total = st.sums.pair_bytes;
@@ -580,7 +600,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 // through aligned LDS dwords + v_alignbyte), single bytes at the two ends
                 const int wv = tid >> 6, lane = tid & 63;
                 for (uint32_t i = first_idx + wv; i < NLe; i += NT / 64) {
-                    if (!(st.bits[i] & LB_EMIT)) continue;
+                    if (!mask_bit(st.m_emit, i)) continue;
                     const uint32_t src = st.off16[i], len = fast_line_sam(st, G, i);
                     uint8_t* dst = s_out.sam + gos + st.u.g.x_sam[i];
                     const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);

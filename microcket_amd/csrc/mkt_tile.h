@@ -270,10 +270,12 @@ template <class Cfg> MKT_HD bool is_start(const TileState<Cfg>& st, const TextVi
 MKT_HD uint32_t lds_inc(uint32_t* p) { return atomicAdd(p, 1u); }
 MKT_HD void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 MKT_HD void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+MKT_HD void lds_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
 #else
 MKT_HD uint32_t lds_inc(uint32_t* p) { return (*p)++; }
 MKT_HD void lds_add(uint32_t* p, uint32_t v) { *p += v; }
 MKT_HD void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+MKT_HD void lds_or64(uint64_t* p, uint64_t v) { *p |= v; }
 #endif
 
 struct GroupWalk {

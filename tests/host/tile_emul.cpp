@@ -39,6 +39,11 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     for (uint32_t i = 0; i < NL; ++i) fast_parse(st, tv, P, G, i);
     const uint32_t NLe = fast_nle(st);
     const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe, end_idx = st.end_idx < NLe ? st.end_idx : NLe;
+    fast_build_masks(st);                                      // the kernel: ballots after fast_parse
+    for (int k = 0; k < 4; ++k) st.m_start[k] = 0;
+    if (!st.abn)
+        for (uint32_t i = 0; i < NLe; ++i)                     // the kernel: one lane per line, ballot
+            if (mask_bit(st.m_surv, i) && i >= first_idx && fast_is_start(st, tv, G, i)) st.m_start[i >> 6] |= 1ull << (i & 63);
     if (!st.abn) for (uint32_t i = first_idx; i < end_idx; ++i) fast_group(st, tv, P, G, i);
     if (st.abn) return false;
     TileSums s = {0, 0, 0, 0, 0};
@@ -61,7 +66,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     while (tile_groups.size() <= t) tile_groups.push_back(0);
     tile_groups[t] = run.groups;
     TileLast tl = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = first_idx; i < end_idx; ++i) { fast_account(st, out, t, i); fast_last(st, &tl, i); }
+    for (uint32_t i = first_idx; i < end_idx; ++i) { fast_account(st, out, t, i); fast_last(st, G, &tl, i); }
     // the kernel writes aligned dwords (fast_pair_bytes4) plus byte-wise ends: exercise both forms
     for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = fast_pair_byte(st, k);
     for (uint32_t k = (t % 3); k < s.pair_bytes; k += 4) {
@@ -71,7 +76,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     }
     if (P.write_sam)
         for (uint32_t i = first_idx; i < NLe; ++i)
-            if (st.bits[i] & LB_EMIT) memcpy(out.sam + run.sam_bytes + g.x_sam[i], st.win + st.off16[i], fast_line_sam(st, G, i));
+            if (mask_bit(st.m_emit, i)) memcpy(out.sam + run.sam_bytes + g.x_sam[i], st.win + st.off16[i], fast_line_sam(st, G, i));
     if (tl.valid) res.last = tl;
     for (int c = 0; c < (int)C_COUNT; ++c) res.counters[c] += st.cnt[c];
     run.groups += s.groups; run.emitted += s.emitted; run.sc += s.sc; run.pair_bytes += s.pair_bytes; run.sam_bytes += s.sam_bytes;
