@@ -217,14 +217,12 @@ MKT_HD uint32_t win_parse_uint(const TextView& tv, uint32_t rr, uint32_t len, bo
 // produce; PF_LONG when the six fields do not end inside the first 128 bytes (the caller uses
 // parse_record); PF_CUT when the window ends before the sixth field does.
 enum { PF_OK = 1, PF_LONG = 0, PF_CUT = -1 };
-MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r, uint64_t ws0, uint64_t ws1, uint32_t L) {
-    rec_clear(r, off);
-    const uint32_t rr = off - tv.w0;
-    if (rr >= tv.wlen) return PF_CUT;
-    const uint32_t avail = tv.wlen - rr;
+// core: the line's bytes are tv.win[rr ...]; `avail` of them can be read, the block ends `reach` bytes after the line start
+MKT_HD int parse_record_core(const TextView& tv, uint32_t rr, const Params& P, Rec& r, uint64_t ws0, uint64_t ws1, uint32_t L,
+                             uint32_t avail, uint32_t reach) {
     uint32_t lim = avail < 128u ? avail : 128u;
     if (L < lim) lim = L;
-    const bool terminated = (L < 128u && lim == L) || (off + lim == tv.n);        // the line really ends at lim
+    const bool terminated = (L < 128u && lim == L) || (lim == reach);              // the line really ends at lim
     const uint64_t m0 = lim >= 64u ? ~0ull : ((1ull << lim) - 1ull);
     const uint64_t m1 = lim <= 64u ? 0ull : (lim >= 128u ? ~0ull : ((1ull << (lim - 64u)) - 1ull));
     const uint64_t n0 = ~ws0 & m0, n1 = ~ws1 & m1;                                // token bytes
@@ -259,6 +257,12 @@ MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, 
     cw.end(r);
     r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;
     return PF_OK;
+}
+MKT_HD int parse_record_fast(const TextView& tv, uint32_t off, const Params& P, Rec& r, uint64_t ws0, uint64_t ws1, uint32_t L) {
+    rec_clear(r, off);
+    const uint32_t rr = off - tv.w0;
+    if (rr >= tv.wlen) return PF_CUT;
+    return parse_record_core(tv, rr, P, r, ws0, ws1, L, tv.wlen - rr, tv.n - off);
 }
 
 // the same, with the head bitmaps taken from the window-wide bitmaps (generic kernel)

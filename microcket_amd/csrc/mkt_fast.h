@@ -1,15 +1,20 @@
 // mkt_fast.h -- the lean tile path of the fused sam2pairs kernel (k_fast in mkt_kernels.hip).
 //
 // Same algorithm as mkt_tile.h, restricted to what well-formed name-grouped SAM looks like so that
-// the hot kernel carries no generic code: every line's six fields end inside its first 128 bytes
-// and inside the window, every group opened in the tile closes inside the window, and the previous
-// surviving line sits in the back halo.  A tile that violates any of this sets `abn` and is left
-// untouched: the host runs the generic kernel (k_tiles, mkt_tile.h) over the list of such tiles.
-// Outputs go to atomically allocated ranges, so the two kernels compose freely.
+// the hot kernel carries no generic code: every line's six fields end inside its first ~112 bytes,
+// every group opened in the tile closes inside the window, and the previous surviving line sits in
+// the back halo.  A tile that violates any of this sets `abn` and is left untouched: the host runs
+// the generic kernel (k_tiles, mkt_tile.h) over the list of such tiles.  Outputs go to atomically
+// allocated ranges, so the two kernels compose freely.
 //
-// State is packed (16-bit window-relative offsets, 8-bit field lengths) to keep one tile at about
-// 36 KB of LDS: four workgroups per CU.  The phase functions are host+device so that
-// tests/host/tile_emul.cpp checks this logic on the CPU as well.
+// LDS holds only what the parser reads: the HEAD of every line (the HEADB = 128 bytes of the eight
+// aligned 16-byte chunks that start at the chunk holding the line's first byte).  SEQ / QUAL / tags,
+// 60 % of the bytes, stream through registers once for the newline scan and never touch LDS, so a
+// 32 KB tile (+ halos) costs 20 KB of LDS instead of 38 KB and twice as many lines are in flight per
+// CU.  `off16` are offsets into that compact head store (what all text code uses); `goff` are the
+// true window-relative line starts (geometry, line lengths).  State is packed (16-bit offsets,
+// 8-bit field lengths): one tile is about 36 KB of LDS, four workgroups per CU.  The phase functions
+// are host+device so that tests/host/tile_emul.cpp checks this logic on the CPU as well.
 #pragma once
 #include "mkt_tile.h"
 
@@ -21,27 +26,31 @@ struct FastCfg {
     static constexpr int MW = (W + 63) / 64 + 3;
     static constexpr int GCAP = 96;                  // emitting groups per tile (more: generic kernel)
     static constexpr int NV16 = (W + 15) / 16 + 8;   // 16-byte vectors of the window (+ padding)
+    static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
+    static constexpr int HW = LCAP_ * HEADB;         // bytes of the head store
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
+    static_assert(LCAP_ * 128 < 65536, "head-store offsets are 16 bit");
 };
 
 constexpr uint8_t LB_EMIT = 8;          // line belongs to an emitting group (its bytes go to the .sam)
 
 template <class Cfg>
 struct FastState {
-    alignas(16) uint8_t win[Cfg::W + 16];
+    alignas(16) uint8_t win[Cfg::HW + 16];           // line heads, HEADB bytes per line
     // per line of the window
     uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP];
     uint32_t right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP];
-    uint16_t off16[Cfg::LCAP];           // line start, window relative
+    uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HEADB + (goff & 15)
+    uint16_t goff[Cfg::LCAP];            // line start, window relative
     uint16_t flag[Cfg::LCAP];
     uint8_t qn_off[Cfg::LCAP], qn_len[Cfg::LCAP], rn_off[Cfg::LCAP], rn_len[Cfg::LCAP], segCnt[Cfg::LCAP], bits[Cfg::LCAP];
     union alignas(16) Phase {
         struct {                                               // while parsing
             uint16_t nl16[Cfg::NV16];                          // newline bits, one u16 per 16 window bytes (line table only)
-            alignas(8) uint16_t hmask[Cfg::LCAP][12];          // per line: whitespace bits of the 9 aligned 16-byte chunks that
-        } m;                                                   //   cover its first 128 bytes ([0..3], [4..7], [8] read as words)
+            alignas(8) uint16_t hmask[Cfg::LCAP][Cfg::HCH];    // per line: whitespace bits of its head chunks
+        } m;
         struct {                                               // afterwards, indexed by the group's first line / by line
             uint32_t g_info[Cfg::LCAP], g_slen[Cfg::LCAP];
             uint32_t x_sam[Cfg::LCAP];                         // per LINE: offset of its bytes in the tile's .sam output
@@ -76,7 +85,8 @@ template <class Cfg> MKT_HD TileGeom fast_geom(uint32_t tile, uint32_t n) {
 }
 template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G) {
     TextView tv;
-    tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = G.w0; tv.wlen = G.w1 - G.w0; tv.nlm = nullptr; tv.wsm = nullptr;
+    (void)G;                                          // text offsets of the lean path are head-store offsets
+    tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = 0; tv.wlen = Cfg::HW; tv.nlm = nullptr; tv.wsm = nullptr;
     return tv;
 }
 template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
@@ -90,7 +100,7 @@ template <class Cfg> MKT_HD uint32_t fast_nle(const FastState<Cfg>& st) {
     return (st.NL && (st.bits[st.NL - 1] & LB_CUT)) ? st.NL - 1u : st.NL;
 }
 template <class Cfg> MKT_HD uint32_t fast_line_end(const FastState<Cfg>& st, const TileGeom& G, uint32_t i) {
-    return i + 1 < st.NL ? G.w0 + st.off16[i + 1] - 1u : st.last_line_end;
+    return i + 1 < st.NL ? G.w0 + st.goff[i + 1] - 1u : st.last_line_end;
 }
 
 // whitespace bits (bit b <-> byte b) of the 16 window bytes starting at window offset r0 (multiple of 16)
@@ -99,34 +109,43 @@ MKT_HD uint32_t ws_bits16_ref(const uint8_t* win, uint32_t r0, uint32_t wlen) {
     for (uint32_t b = 0; b < 16u; ++b) if (r0 + b < wlen && is_ws(win[r0 + b])) m |= 1u << b;
     return m;
 }
-// the two 64-bit whitespace words of line i's first 128 bytes, from its head-mask row
+// the two 64-bit whitespace words of line i's head (bit k <-> byte k of the line), from its head-mask row
 template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t i, uint64_t& ws0, uint64_t& ws1) {
     const uint64_t* row = reinterpret_cast<const uint64_t*>(st.u.m.hmask[i]);
-    const uint64_t A = row[0], B = row[1], C = row[2] & 0xFFFFull;
+    const uint64_t A = row[0], B = row[1];
     const uint32_t sh = st.off16[i] & 15u;
     ws0 = sh ? ((A >> sh) | (B << (64u - sh))) : A;
-    ws1 = sh ? ((B >> sh) | (C << (64u - sh))) : B;
+    ws1 = B >> sh;
+}
+// one head chunk: the 16 text bytes at window offset r0 (multiple of 16); bytes at or past the block end read as 0
+template <class Cfg> MKT_HD void fast_head_chunk_ref(FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G, uint32_t i, uint32_t c) {
+    const uint32_t r0 = (st.goff[i] & ~15u) + 16u * c;
+    uint32_t m = 0;
+    for (uint32_t b = 0; b < 16u; ++b) {
+        const uint64_t g = (uint64_t)G.w0 + r0 + b;
+        const uint8_t ch = g < n ? text[g] : 0;
+        st.win[i * Cfg::HEADB + 16u * c + b] = ch;
+        if (g < n && is_ws(ch)) m |= 1u << b;
+    }
+    st.u.m.hmask[i][c] = (uint16_t)m;
 }
 
 // ---- parse line i ------------------------------------------------------------------------------
 template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
-    const uint32_t off = G.w0 + st.off16[i];
-    if (i + 1 == st.NL) {
-        uint32_t e;
-        if (G.w1 - 1 >= off && tv.win[G.w1 - 1 - G.w0] == '\n') e = G.w1 - 1;
-        else e = G.w1 >= tv.n ? tv.n : kUnknown;
-        st.last_line_end = e;
-    }
-    if (off >= G.t0 && (i == 0 || G.w0 + st.off16[i - 1] < G.t0)) st.first_idx = i;
-    if (off >= G.t1 && (i == 0 || G.w0 + st.off16[i - 1] < G.t1)) st.end_idx = i;
+    const uint32_t gl = G.w0 + st.goff[i];                         // line start in the block
+    const uint32_t off = st.off16[i];                              // ... and in the head store
+    if (gl >= G.t0 && (i == 0 || G.w0 + st.goff[i - 1] < G.t0)) st.first_idx = i;
+    if (gl >= G.t1 && (i == 0 || G.w0 + st.goff[i - 1] < G.t1)) st.end_idx = i;
     Rec r;
     uint64_t ws0, ws1;
     fast_head_ws(st, i, ws0, ws1);
     const uint32_t le = fast_line_end(st, G, i);                   // from the line table: no newline bitmap needed
-    const int pf = parse_record_fast(tv, off, P, r, ws0, ws1, le == kUnknown ? 0xFFFFu : le - off);
+    const uint32_t room = (uint32_t)Cfg::HEADB - (off & 15u), reach = tv.n - gl;
+    rec_clear(r, off);
+    const int pf = parse_record_core(tv, off, P, r, ws0, ws1, le == kUnknown ? 0xFFFFu : le - gl, room < reach ? room : reach, reach);
     if (pf != PF_OK) {
-        if (pf == PF_CUT && off >= G.t1) st.bits[i] = LB_CUT;      // last halo line, cut by the window: ignored
-        else { st.bits[i] = 0; st.abn = 1; }                       // fields beyond 128 bytes: generic kernel
+        if (gl >= G.t1 && i + 1 == st.NL && G.w1 < tv.n) st.bits[i] = LB_CUT;    // last halo line: ignored (a group reaching it is deferred)
+        else { st.bits[i] = 0; st.abn = 1; }                       // fields beyond the head: generic kernel
         return;
     }
     st.pos[i] = r.pos; st.lclip[i] = (uint32_t)r.lclip; st.rclip[i] = (uint32_t)r.rclip; st.mappable[i] = (uint32_t)r.mappable;
@@ -136,13 +155,14 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     st.segCnt[i] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
     uint8_t b = r.survive ? LB_SURVIVE : 0;
     // the emitter copies QNAME / RNAME together with the separator that follows them: it must be a tab
-    if (tv.win[off + r.qn_off + r.qn_len - G.w0] != '\t' || tv.win[off + r.rn_off + r.rn_len - G.w0] != '\t') st.abn = 1;
+    if (tv.win[off + r.qn_off + r.qn_len] != '\t' || tv.win[off + r.rn_off + r.rn_len] != '\t') st.abn = 1;
     if (i > 0) {
         // same QNAME token as the line before: its first token must start at its first byte
-        const uint32_t poff = G.w0 + st.off16[i - 1];
+        const uint32_t poff = st.off16[i - 1];
         const uint32_t ql = r.qn_len;
-        if (is_ws(tv.win[poff - G.w0])) st.abn = 1;
-        else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql - G.w0])) b |= LB_EQPREV;
+        if (is_ws(tv.win[poff])) st.abn = 1;
+        else if (ql + 1u > (uint32_t)Cfg::HEADB - (poff & 15u)) st.abn = 1;          // beyond the previous line's head
+        else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql])) b |= LB_EQPREV;
     }
     st.bits[i] = b;
 }
@@ -212,16 +232,16 @@ template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextVie
     // every line in (p, i] has the QNAME token of the line before it  =>  equal by transitivity
     if (((~mask_win_back(st.m_eqp, i)) >> (64u - d)) == 0ull) return false;
     if (d == 1u) return true;                         // adjacent surviving lines with different tokens
-    return !text_eq<true>(tv, G.w0 + st.off16[i] + st.qn_off[i], st.qn_len[i], G.w0 + st.off16[p] + st.qn_off[p], st.qn_len[p]);
+    return !text_eq<true>(tv, (uint32_t)st.off16[i] + st.qn_off[i], st.qn_len[i], (uint32_t)st.off16[p] + st.qn_off[p], st.qn_len[p]);
 }
 
-template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, const TileGeom& G, uint32_t idx) {
+template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, uint32_t idx) {
     Seg s;
     s.segCnt = st.segCnt[idx]; s.lclip = (int32_t)st.lclip[idx]; s.rclip = (int32_t)st.rclip[idx]; s.mappable = (int32_t)st.mappable[idx];
     s.left0 = (int32_t)st.pos[idx]; s.left1 = (int32_t)st.left1[idx]; s.right0 = (int32_t)st.right0[idx]; s.right1 = (int32_t)st.right1[idx];
     s.rightLast = s.segCnt == 2 ? s.right1 : s.right0;
     s.flag = st.flag[idx]; s.pos = st.pos[idx];
-    s.chr_off = G.w0 + st.off16[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];
+    s.chr_off = (uint32_t)st.off16[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];      // head-store offset
     return s;
 }
 
@@ -230,9 +250,6 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
     auto& g = st.u.g;
     g.g_info[i] = 0; g.g_plen[i] = 0; g.g_slen[i] = 0;
     if (!mask_bit(st.m_start, i)) return;
-#if defined(MKT_DIAG_NOWALK)
-    g.g_info[i] = GI_START; return;
-#endif
     const uint32_t NLe = fast_nle(st);
     // lines i .. i+63 as one word per mask; the group ends before the next start bit
     const uint64_t nx = mask_win(st.m_start, i) >> 1;
@@ -263,17 +280,13 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
     // a member whose line end is not known (last line of the table) or that lacks its final newline: generic kernel
     if (i + 64u - clz64(mem) == st.NL && (st.last_line_end == kUnknown || st.last_line_end >= tv.n)) st.abn = 1;
     Verdict v;
-#if defined(MKT_DIAG_NOCLASSIFY)
-    v = verdict_none(C_TRANS); v.emit = nmem >= 2; v.chrA_off = v.chrB_off = G.w0 + st.off16[i] + st.rn_off[i]; v.chrA_len = v.chrB_len = st.rn_len[i]; v.posA = st.pos[i]; v.posB = st.pos[i] + nmem;
-    if (false)
-#endif
     {
-        Seg a = sa != 0xFFFFu ? fast_seg(st, G, sa) : seg_zero();
-        Seg b = sb != 0xFFFFu ? fast_seg(st, G, sb) : seg_zero();
+        Seg a = sa != 0xFFFFu ? fast_seg(st, sa) : seg_zero();
+        Seg b = sb != 0xFFFFu ? fast_seg(st, sb) : seg_zero();
         if (P.mode == MODE_FLASH) v = classify_flash<true>(tv, nmem, a, b, P.ratio);
         else {
-            Seg c = sc != 0xFFFFu ? fast_seg(st, G, sc) : seg_zero();
-            Seg d = sd != 0xFFFFu ? fast_seg(st, G, sd) : seg_zero();
+            Seg c = sc != 0xFFFFu ? fast_seg(st, sc) : seg_zero();
+            Seg d = sd != 0xFFFFu ? fast_seg(st, sd) : seg_zero();
             v = classify_unc<true>(tv, n1, n2, a, b, c, d, P.ratio);
         }
     }
@@ -287,11 +300,10 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
         g.g_slot[i] = (uint8_t)slot;
         const uint32_t ql = st.qn_len[i], dA = dec_digits(v.posA), dB = dec_digits(v.posB);
         g.l_qa[slot] = (uint16_t)(st.off16[i] + st.qn_off[i]);
-        g.l_ca[slot] = (uint16_t)(v.chrA_off - G.w0); g.l_cb[slot] = (uint16_t)(v.chrB_off - G.w0);
+        g.l_ca[slot] = (uint16_t)v.chrA_off; g.l_cb[slot] = (uint16_t)v.chrB_off;
         const uint32_t e0 = ql + 1u, e1 = e0 + v.chrA_len + 1u, e2 = e1 + dA + 1u, e3 = e2 + v.chrB_len + 1u;
         g.l_e0[slot] = (uint16_t)e0; g.l_e1[slot] = (uint16_t)e1; g.l_e2[slot] = (uint16_t)e2; g.l_e3[slot] = (uint16_t)e3;
         g.l_posA[slot] = v.posA; g.l_posB[slot] = v.posB;
-#if !defined(MKT_DIAG_NOLIT)
         {   // literals "<posA>\t" and "<posB>\t<sA>\t<sB>\n", text order = little-endian byte order
             uint64_t w0, w1;
             dec_lit(v.posA, dA, (uint64_t)'\t', w0, w1);
@@ -300,7 +312,6 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
             dec_lit(v.posB, dB, tail, w0, w1);
             g.l_litB[slot][0] = w0; g.l_litB[slot][1] = w1;
         }
-#endif
         g.g_plen[i] = (uint16_t)(e3 + dB + 5u);
         if (P.write_sam) {                             // the group's surviving lines go to the .sam
             const uint32_t w = i >> 6, sh = i & 63u;
@@ -314,7 +325,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
 // bytes line i contributes to the tile's .sam output
 template <class Cfg> MKT_HD uint32_t fast_line_sam(const FastState<Cfg>& st, const TileGeom& G, uint32_t i) {
     if (!mask_bit(st.m_emit, i)) return 0u;
-    return fast_line_end(st, G, i) + 1u - (G.w0 + st.off16[i]);
+    return fast_line_end(st, G, i) + 1u - (G.w0 + st.goff[i]);
 }
 
 // ---- account for the group opened by line i (counters, self-circle entry) ------------------------
@@ -334,7 +345,7 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
         const uint64_t k = (uint64_t)st.base.emitted + g.x_emit[i];
         if (k < out.keys_cap) {
             TextView tv;
-            tv.g = nullptr; tv.n = 0; tv.win = st.win; tv.w0 = 0; tv.wlen = Cfg::W + 16; tv.nlm = nullptr; tv.wsm = nullptr;
+            tv.g = nullptr; tv.n = 0; tv.win = st.win; tv.w0 = 0; tv.wlen = Cfg::HW; tv.nlm = nullptr; tv.wsm = nullptr;
             uint32_t err = 0;
             const uint32_t sa = chr_slot(out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
             const uint32_t sb = chr_slot(out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
@@ -354,7 +365,7 @@ template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, const TileG
         uint32_t sb = 0;
         if (mask_bit(st.m_emit, i)) {
             const uint32_t end = mask_next(st.m_start, i + 1u, fast_nle(st));
-            for (uint32_t k = i; k < end; ++k) if (mask_bit(st.m_surv, k)) sb += fast_line_end(st, G, k) + 1u - (G.w0 + st.off16[k]);
+            for (uint32_t k = i; k < end; ++k) if (mask_bit(st.m_surv, k)) sb += fast_line_end(st, G, k) + 1u - (G.w0 + st.goff[k]);
         }
         tl->sam_bytes = sb;
     }

@@ -18,10 +18,10 @@
 #define MKT_RR 4          // waves that share the group phase of a tile (lines dealt round-robin)
 #endif
 #ifndef MKT_LEAN_TILE
-#define MKT_LEAN_TILE 16384
+#define MKT_LEAN_TILE 32768
 #define MKT_LEAN_HB 2048
 #define MKT_LEAN_HF 4096
-#define MKT_LEAN_LCAP 192
+#define MKT_LEAN_LCAP 160
 #endif
 
 namespace mkt {
@@ -401,38 +401,29 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         const uint32_t nvec = (wlen + 15u) >> 4;
         const TextView tv = fast_view(st, a.text, n, G);
 
-        // ---- stage window in LDS; newline bits (one u16 per 16 bytes) for the line table ------------
+        // ---- newline bits (one u16 per 16 bytes) of the window: the text streams through registers only
         {
-            constexpr int LPT = (NVEC + 1 + NT - 1) / NT;      // 16-byte vectors per thread (+1: zero pad vector)
-            uint4 x[LPT];
+            constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread
+            constexpr int BATCH = 5;
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {                    // all loads first ...
-                const uint32_t v = tid + k * NT;
-                const uint32_t go = G.w0 + (v << 4);
-                x[k] = make_uint4(0, 0, 0, 0);
-                // the text buffer is readable up to the next multiple of 16 (include/mkt.h); bytes past n are cleared below
-                if (v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + go);
-            }
+            for (int k0 = 0; k0 < LPT; k0 += BATCH) {
+                uint4 x[BATCH];
 #pragma unroll
-            for (int k = 0; k < LPT; ++k) {                    // ... then the math
-                const uint32_t v = tid + k * NT;
-                if (v > nvec || v >= (uint32_t)Cfg::NV16) continue;
-                uint32_t mnl = 0;
-                if (v < nvec) {
-                    const uint32_t r0 = v << 4;
-                    if (r0 + 16u > wlen) {                     // last vector of the block: clear the bytes past the end
-                        const uint32_t keep = wlen - r0;       // 1..15
-                        uint32_t* w = reinterpret_cast<uint32_t*>(&x[k]);
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const uint32_t lo = (uint32_t)d * 4u;
-                            w[d] = keep >= lo + 4u ? w[d] : (keep > lo ? (w[d] & ((1u << ((keep - lo) * 8u)) - 1u)) : 0u);
-                        }
-                    }
-                    mnl = pack16(nl_flags(x[k].x), nl_flags(x[k].y), nl_flags(x[k].z), nl_flags(x[k].w));
+                for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
+                    const uint32_t v = tid + (k0 + k) * NT;
+                    x[k] = make_uint4(0, 0, 0, 0);
+                    // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
+                    if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
-                *reinterpret_cast<uint4*>(&st.win[v << 4]) = x[k];      // v == nvec: the zero pad vector
-                nlmask[v] = (uint16_t)mnl;
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {              // ... then the math
+                    const uint32_t v = tid + (k0 + k) * NT;
+                    if (k0 + k >= LPT || v >= nvec) continue;
+                    uint32_t mnl = pack16(nl_flags(x[k].x), nl_flags(x[k].y), nl_flags(x[k].z), nl_flags(x[k].w));
+                    const uint32_t r0 = v << 4;
+                    if (r0 + 16u > wlen) mnl &= (1u << (wlen - r0)) - 1u;      // bytes past the end of the window / block
+                    nlmask[v] = (uint16_t)mnl;
+                }
             }
         }
         __syncthreads();
@@ -441,7 +432,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
 
         // ---- line table ----------------------------------------------------------------------------
         {
-            auto line_bits = [&](uint32_t v) -> uint32_t {
+            auto line_bits = [&](uint32_t v) -> uint32_t {     // a newline at the window's last byte opens no line
                 uint32_t m = nlmask[v];
                 const uint32_t r0 = v << 4;
                 if (r0 + 16u > wlen - 1u) { const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u; m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u); }
@@ -463,26 +454,47 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                     uint32_t m = line_bits(v0 + k);
                     while (m) {
                         const uint32_t b = __builtin_ctz(m);
-                        st.off16[idx++] = (uint16_t)(((v0 + k) << 4) + b + 1u);
+                        const uint32_t r = ((v0 + k) << 4) + b + 1u;
+                        st.goff[idx] = (uint16_t)r;
+                        st.off16[idx] = (uint16_t)(idx * (uint32_t)Cfg::HEADB + (r & 15u));
+                        ++idx;
                         m &= m - 1u;
                     }
                 }
-                if (tid == 0) { if (lead) st.off16[0] = 0; st.NL = NLt; st.first_idx = NLt; st.end_idx = NLt; }
+                if (tid == 0) {
+                    if (lead) { st.goff[0] = 0; st.off16[0] = 0; }
+                    st.NL = NLt; st.first_idx = NLt; st.end_idx = NLt;
+                    // end of the table's last line: the window's last byte when that is a newline
+                    const bool nl_last = (nlmask[(wlen - 1u) >> 4] >> ((wlen - 1u) & 15u)) & 1u;
+                    st.last_line_end = nl_last ? G.w1 - 1u : (G.w1 >= n ? n : kUnknown);
+                }
             }
         }
         __syncthreads();
         const uint32_t NL = st.NL;
         STAMP(2);
         STOP_AFTER(2)
-        // ---- whitespace bits, only where a line's six fields can be: the 9 aligned chunks over its first 128 bytes
-        for (uint32_t it = tid; it < NL * 9u; it += NT) {
-            const uint32_t i = it / 9u, c = it - i * 9u;
-            const uint32_t r0 = (st.off16[i] & ~15u) + (c << 4);
-            uint32_t m = 0;
-            if (r0 + 16u <= (uint32_t)(Cfg::W + 16)) {
-                const uint4 q = *reinterpret_cast<const uint4*>(&st.win[r0]);
-                m = pack16(ws_flags(q.x), ws_flags(q.y), ws_flags(q.z), ws_flags(q.w));
+        // ---- line heads: the eight aligned 16-byte chunks from each line's first byte on (L2 hits: the bytes were
+        //      just streamed), with their whitespace bits
+        for (uint32_t it = tid; it < NL * (uint32_t)Cfg::HCH; it += NT) {
+            const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
+            const uint64_t g0 = (uint64_t)G.w0 + (st.goff[i] & ~15u) + (c << 4);
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (g0 < n) {
+                q = *reinterpret_cast<const uint4*>(a.text + g0);
+                if (g0 + 16u > n) {                            // last vector of the block: clear the bytes past the end
+                    const uint32_t keep = (uint32_t)(n - g0);  // 1..15
+                    uint32_t* w = reinterpret_cast<uint32_t*>(&q);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t lo = (uint32_t)d * 4u;
+                        w[d] = keep >= lo + 4u ? w[d] : (keep > lo ? (w[d] & ((1u << ((keep - lo) * 8u)) - 1u)) : 0u);
+                    }
+                }
             }
+            *reinterpret_cast<uint4*>(&st.win[i * (uint32_t)Cfg::HEADB + (c << 4)]) = q;
+            uint32_t m = pack16(ws_flags(q.x), ws_flags(q.y), ws_flags(q.z), ws_flags(q.w));
+            if (g0 + 16u > n) m &= g0 < n ? (1u << (uint32_t)(n - g0)) - 1u : 0u;       // cleared bytes are not whitespace
             st.u.m.hmask[i][c] = (uint16_t)m;
         }
         __syncthreads();
@@ -596,25 +608,26 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         if (P.write_sam && st.sums.sam_bytes) {
             const uint64_t gos = st.base.sam_bytes;
             if (gos + st.sums.sam_bytes <= s_out.sam_cap) {
-                // one wave per emitting line: 16-byte stores on destination-aligned chunks (window bytes come
-                // through aligned LDS dwords + v_alignbyte), single bytes at the two ends
+                // one wave per emitting line, straight from the text in global memory (L2): 16-byte stores on
+                // destination-aligned chunks, single bytes at the two ends
                 const int wv = tid >> 6, lane = tid & 63;
                 for (uint32_t i = first_idx + wv; i < NLe; i += NT / 64) {
                     if (!mask_bit(st.m_emit, i)) continue;
-                    const uint32_t src = st.off16[i], len = fast_line_sam(st, G, i);
+                    const uint8_t* src = a.text + G.w0 + st.goff[i];
+                    const uint32_t len = fast_line_sam(st, G, i);
                     uint8_t* dst = s_out.sam + gos + st.u.g.x_sam[i];
                     const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
                     const uint32_t h = head < len ? head : len;
-                    if ((uint32_t)lane < h) dst[lane] = st.win[src + lane];
+                    if ((uint32_t)lane < h) dst[lane] = src[lane];
                     const uint32_t nv = (len - h) >> 4;
                     for (uint32_t v = lane; v < nv; v += 64) {
                         const uint32_t o = h + (v << 4);
                         uint4 x;
-                        x.x = win_load4(tv, src + o); x.y = win_load4(tv, src + o + 4u); x.z = win_load4(tv, src + o + 8u); x.w = win_load4(tv, src + o + 12u);
+                        __builtin_memcpy(&x, src + o, 16);
                         *reinterpret_cast<uint4*>(dst + o) = x;
                     }
                     const uint32_t t0 = h + (nv << 4);
-                    if ((uint32_t)lane < len - t0) dst[t0 + lane] = st.win[src + t0 + lane];
+                    if ((uint32_t)lane < len - t0) dst[t0 + lane] = src[t0 + lane];
                 }
             }
         }

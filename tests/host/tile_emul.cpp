@@ -25,16 +25,18 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     const TileGeom G = fast_geom<FC>(t, n);
     const uint32_t wlen = G.w1 - G.w0;
     memset(st.win, 0, sizeof st.win);
-    memcpy(st.win, text + G.w0, wlen);
     memset(&st.u, 0, sizeof st.u);
     const TextView tv = fast_view(st, text, n, G);
+    const uint8_t* win = text + G.w0;                          // the kernel streams these bytes through registers
     uint32_t NL = 0;
-    if (G.w0 == 0) st.off16[NL++] = 0;
+    auto add_line = [&](uint32_t r) { st.goff[NL] = (uint16_t)r; st.off16[NL] = (uint16_t)(NL * FC::HEADB + (r & 15u)); ++NL; };
+    if (G.w0 == 0) add_line(0);
     for (uint32_t r = 0; r + 1 < wlen; ++r)
-        if (st.win[r] == '\n') { if (NL == (uint32_t)FC::LCAP) return false; st.off16[NL++] = (uint16_t)(r + 1); }
-    // head masks: whitespace bits of the 9 aligned chunks covering each line's first 128 bytes (k_fast: one lane per chunk)
+        if (win[r] == '\n') { if (NL == (uint32_t)FC::LCAP) return false; add_line(r + 1); }
+    st.last_line_end = win[wlen - 1] == '\n' ? G.w1 - 1u : (G.w1 >= n ? n : kUnknown);
+    // line heads with their whitespace bits (k_fast: one lane per 16-byte chunk)
     for (uint32_t i = 0; i < NL; ++i)
-        for (uint32_t c = 0; c < 9; ++c) st.u.m.hmask[i][c] = (uint16_t)ws_bits16_ref(st.win, (st.off16[i] & ~15u) + 16u * c, wlen);
+        for (uint32_t c = 0; c < (uint32_t)FC::HCH; ++c) fast_head_chunk_ref(st, text, n, G, i, c);
     st.NL = NL; st.first_idx = NL; st.end_idx = NL;
     for (uint32_t i = 0; i < NL; ++i) fast_parse(st, tv, P, G, i);
     const uint32_t NLe = fast_nle(st);
@@ -76,7 +78,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     }
     if (P.write_sam)
         for (uint32_t i = first_idx; i < NLe; ++i)
-            if (mask_bit(st.m_emit, i)) memcpy(out.sam + run.sam_bytes + g.x_sam[i], st.win + st.off16[i], fast_line_sam(st, G, i));
+            if (mask_bit(st.m_emit, i)) memcpy(out.sam + run.sam_bytes + g.x_sam[i], text + G.w0 + st.goff[i], fast_line_sam(st, G, i));
     if (tl.valid) res.last = tl;
     for (int c = 0; c < (int)C_COUNT; ++c) res.counters[c] += st.cnt[c];
     run.groups += s.groups; run.emitted += s.emitted; run.sc += s.sc; run.pair_bytes += s.pair_bytes; run.sam_bytes += s.sam_bytes;
