@@ -13,7 +13,7 @@ of the hot path over the whole resident data set (all blocks).  N > 1: every ran
 exchange is the group-count all_gather + 8-counter all_reduce at the end (quirks Q1/Q2).
 
 `value` = pairs processed by all ranks / wall time of K steps (max over ranks), inputs resident.
-`roofline`: the fused tile kernel (k_tiles), algorithmic bytes (SAM bytes in + .pairs bytes out)
+`roofline`: the fused tile kernel (k_fast), algorithmic bytes (SAM bytes in + .pairs bytes out)
 per launch over its HIP-event launch duration, against 8 TB/s HBM.
 `cpu_baseline`: the reference itself (oracle/_ref/sam2pairs.ref, built from /root/reference by
 oracle/Makefile) timed on this host on a bounded sample of the same data (first blocks).
@@ -216,7 +216,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_tiles (fused scan/parse/classify/format)",
+                "kernel": "k_fast (fused newline scan / parse / classify / format)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -225,6 +225,8 @@ def main():
                 "launches": tm_launch,
                 "avg_launch_ms": tm_ms / tm_launch if tm_launch else None,
                 "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / tm_launch if tm_launch else None,
+                "tiles": tmg.tiles,
+                "tiles_left_to_generic_kernel": tmg.deferred_tiles,
             },
             "cpu_baseline": cpu,
             "counters": dict(zip(["lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0", "pairs", "pair_bytes"], counters)),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 2
+#define MKT_ABI_VERSION 3
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -89,6 +89,8 @@ typedef struct mkt_timing {
     uint64_t tile_launches;
     uint64_t tile_bytes;       /* SAM bytes those launches consumed */
     double other_ms;           /* memset + finish kernels */
+    uint64_t tiles;            /* tiles processed */
+    uint64_t deferred_tiles;   /* of those, tiles the lean kernel left to the generic kernel */
 } mkt_timing;
 
 typedef struct mkt_ctx mkt_ctx;

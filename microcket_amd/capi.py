@@ -39,7 +39,8 @@ class Out(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("tile_kernel_ms", C.c_double), ("tile_launches", C.c_uint64), ("tile_bytes", C.c_uint64), ("other_ms", C.c_double)]
+    _fields_ = [("tile_kernel_ms", C.c_double), ("tile_launches", C.c_uint64), ("tile_bytes", C.c_uint64), ("other_ms", C.c_double),
+                ("tiles", C.c_uint64), ("deferred_tiles", C.c_uint64)]
 
 
 def lib_path():

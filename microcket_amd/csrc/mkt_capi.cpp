@@ -54,6 +54,7 @@ struct mkt_ctx {
     std::vector<hipEvent_t> ev;          // start/stop pairs of the tile kernel
     std::vector<uint64_t> ev_bytes;
     double folded_ms = 0; uint64_t folded_launches = 0, folded_bytes = 0;
+    uint64_t tiles_total = 0, tiles_deferred = 0;      // lean-kernel tiles / those it left to the generic kernel
     // synth
     char* d_syn = nullptr; size_t syn_cap = 0;
     uint64_t* d_syn_sizes = nullptr; size_t syn_sizes_cap = 0;
@@ -370,7 +371,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         if (!grew) return check_result(c, r);
     }
     // fetch outputs
-    c->acc.add_block(r);
+    c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
     ++c->blocks;
     c->sc_on_device += r.sc;
     if ((rc = drain_sc(c))) return rc;
@@ -473,7 +474,7 @@ int mkt_sync(mkt_ctx* c) {
     for (size_t k = c->res_folded; k < c->res_used; ++k) {
         const BlockResult& r = c->h_res[k];
         if (r.err) { rc = check_result(c, r); break; }      // resident blocks are not retried: fail loudly
-        c->acc.add_block(r);
+        c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
         c->sc_on_device += r.sc;
         ++c->blocks;
     }
@@ -686,11 +687,12 @@ int mkt_format_log(const mkt_stats* st, char* out, size_t cap) {
 int mkt_get_timing(const mkt_ctx* c, mkt_timing* t) {
     if (!c || !t) return MKT_E_ARG;
     t->tile_kernel_ms = c->folded_ms; t->tile_launches = c->folded_launches; t->tile_bytes = c->folded_bytes; t->other_ms = 0;
+    t->tiles = c->tiles_total; t->deferred_tiles = c->tiles_deferred;
     return MKT_OK;
 }
 int mkt_reset_timing(mkt_ctx* c) {
     if (!c) return MKT_E_ARG;
-    c->folded_ms = 0; c->folded_launches = 0; c->folded_bytes = 0;
+    c->folded_ms = 0; c->folded_launches = 0; c->folded_bytes = 0; c->tiles_total = 0; c->tiles_deferred = 0;
     return MKT_OK;
 }
 

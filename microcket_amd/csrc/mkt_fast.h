@@ -20,6 +20,9 @@
 
 namespace mkt {
 
+// geometry of the production lean kernel (also what tests/host/tile_emul.cpp emulates as config 0 / 10)
+constexpr int kLeanTile = 32768, kLeanHB = 2048, kLeanHF = 3072, kLeanLCAP = 160;
+
 template <int TILE_, int HB_, int HF_, int LCAP_>
 struct FastCfg {
     static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
@@ -33,6 +36,9 @@ struct FastCfg {
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
     static_assert(LCAP_ * 128 < 65536, "head-store offsets are 16 bit");
 };
+
+// why a tile is left to the generic kernel (low byte of FastState::abn; any value != 0 defers)
+enum { AB_LCAP = 1, AB_LONG, AB_TAB, AB_PREV_WS, AB_PREV_HEAD, AB_NO_PREV, AB_OPEN_GROUP, AB_LAST_LINE, AB_GCAP, AB_PAIR_BYTES };
 
 constexpr uint8_t LB_EMIT = 8;          // line belongs to an emitting group (its bytes go to the .sam)
 
@@ -145,7 +151,7 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     const int pf = parse_record_core(tv, off, P, r, ws0, ws1, le == kUnknown ? 0xFFFFu : le - gl, room < reach ? room : reach, reach);
     if (pf != PF_OK) {
         if (gl >= G.t1 && i + 1 == st.NL && G.w1 < tv.n) st.bits[i] = LB_CUT;    // last halo line: ignored (a group reaching it is deferred)
-        else { st.bits[i] = 0; st.abn = 1; }                       // fields beyond the head: generic kernel
+        else { st.bits[i] = 0; st.abn = AB_LONG; }                       // fields beyond the head: generic kernel
         return;
     }
     st.pos[i] = r.pos; st.lclip[i] = (uint32_t)r.lclip; st.rclip[i] = (uint32_t)r.rclip; st.mappable[i] = (uint32_t)r.mappable;
@@ -155,13 +161,13 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     st.segCnt[i] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
     uint8_t b = r.survive ? LB_SURVIVE : 0;
     // the emitter copies QNAME / RNAME together with the separator that follows them: it must be a tab
-    if (tv.win[off + r.qn_off + r.qn_len] != '\t' || tv.win[off + r.rn_off + r.rn_len] != '\t') st.abn = 1;
+    if (tv.win[off + r.qn_off + r.qn_len] != '\t' || tv.win[off + r.rn_off + r.rn_len] != '\t') st.abn = AB_TAB;
     if (i > 0) {
         // same QNAME token as the line before: its first token must start at its first byte
         const uint32_t poff = st.off16[i - 1];
         const uint32_t ql = r.qn_len;
-        if (is_ws(tv.win[poff])) st.abn = 1;
-        else if (ql + 1u > (uint32_t)Cfg::HEADB - (poff & 15u)) st.abn = 1;          // beyond the previous line's head
+        if (is_ws(tv.win[poff])) st.abn = AB_PREV_WS;
+        else if (ql + 1u > (uint32_t)Cfg::HEADB - (poff & 15u)) st.abn = AB_PREV_HEAD;          // beyond the previous line's head
         else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql])) b |= LB_EQPREV;
     }
     st.bits[i] = b;
@@ -225,7 +231,7 @@ template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextVie
     const uint64_t sv = mask_win_back(st.m_surv, i) & ~(1ull << 63);      // the 63 lines before line i
     if (!sv) {
         if (G.w0 == 0 && i < 64u) return true;        // first surviving line of the block
-        st.abn = 1;                                   // the previous surviving line is before the window (or > 63 lines back)
+        st.abn = AB_NO_PREV;                                   // the previous surviving line is before the window (or > 63 lines back)
         return false;
     }
     const uint32_t d = clz64(sv), p = i - d;          // previous surviving line
@@ -257,7 +263,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
     if (nx) len = ctz64(nx) + 1u;
     else {
         len = NLe - i;
-        if (G.w1 < tv.n || len > 64u) { st.abn = 1; return; }        // the group may continue past the window
+        if (G.w1 < tv.n || len > 64u) { st.abn = AB_OPEN_GROUP; return; }        // the group may continue past the window
     }
     const uint64_t in = len >= 64u ? ~0ull : ((1ull << len) - 1ull);
     const uint64_t mem = mask_win(st.m_surv, i) & in;                 // bit 0 (line i) is set
@@ -278,7 +284,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
         if (r) sd = i + ctz64(r);
     }
     // a member whose line end is not known (last line of the table) or that lacks its final newline: generic kernel
-    if (i + 64u - clz64(mem) == st.NL && (st.last_line_end == kUnknown || st.last_line_end >= tv.n)) st.abn = 1;
+    if (i + 64u - clz64(mem) == st.NL && (st.last_line_end == kUnknown || st.last_line_end >= tv.n)) st.abn = AB_LAST_LINE;
     Verdict v;
     {
         Seg a = sa != 0xFFFFu ? fast_seg(st, sa) : seg_zero();
@@ -296,7 +302,7 @@ template <class Cfg> MKT_HD void fast_group(FastState<Cfg>& st, const TextView& 
         if (v.sA == '-') info |= GI_SA_MINUS;
         if (v.sB == '-') info |= GI_SB_MINUS;
         const uint32_t slot = lds_inc(&st.nslot);
-        if (slot >= (uint32_t)Cfg::GCAP) { st.abn = 1; return; }
+        if (slot >= (uint32_t)Cfg::GCAP) { st.abn = AB_GCAP; return; }
         g.g_slot[i] = (uint8_t)slot;
         const uint32_t ql = st.qn_len[i], dA = dec_digits(v.posA), dB = dec_digits(v.posB);
         g.l_qa[slot] = (uint16_t)(st.off16[i] + st.qn_off[i]);

@@ -17,11 +17,14 @@
 #ifndef MKT_RR
 #define MKT_RR 4          // waves that share the group phase of a tile (lines dealt round-robin)
 #endif
-#ifndef MKT_LEAN_TILE
-#define MKT_LEAN_TILE 32768
-#define MKT_LEAN_HB 2048
-#define MKT_LEAN_HF 4096
-#define MKT_LEAN_LCAP 160
+#ifndef MKT_LEAN_TILE      // experiments override the geometry of mkt_fast.h
+#define MKT_LEAN_TILE kLeanTile
+#define MKT_LEAN_HB kLeanHB
+#define MKT_LEAN_HF kLeanHF
+#define MKT_LEAN_LCAP kLeanLCAP
+#endif
+#ifndef MKT_LOAD_BATCH
+#define MKT_LOAD_BATCH 5
 #endif
 
 namespace mkt {
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         // ---- newline bits (one u16 per 16 bytes) of the window: the text streams through registers only
         {
             constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread
-            constexpr int BATCH = 5;
+            constexpr int BATCH = MKT_LOAD_BATCH;
 #pragma unroll
             for (int k0 = 0; k0 < LPT; k0 += BATCH) {
                 uint4 x[BATCH];
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             const uint32_t lead = G.w0 == 0 ? 1u : 0u;
             const uint32_t NLt = (uint32_t)total + lead;
             if (NLt > (uint32_t)Cfg::LCAP) {
-                if (tid == 0) { st.abn = 1; st.NL = 0; }
+                if (tid == 0) { st.abn = AB_LCAP; st.NL = 0; }
             } else {
                 uint32_t idx = (uint32_t)ex + lead;
                 for (uint32_t k = 0; k < (uint32_t)VPT; ++k) {
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             if (tid == 0) {
                 st.sums.groups = (uint32_t)(ta & 0xFFFFu); st.sums.emitted = (uint32_t)((ta >> 16) & 0xFFFFu); st.sums.sc = (uint32_t)((ta >> 32) & 0xFFFFu);
                 st.sums.pair_bytes = (uint32_t)tb; st.sums.sam_bytes = tb >> 32;
-                if ((uint32_t)tb > 0xFFFFu) st.abn = 1;          // 16-bit in-tile offsets
+                if ((uint32_t)tb > 0xFFFFu) st.abn = AB_PAIR_BYTES;          // 16-bit in-tile offsets
             }
         }
         __syncthreads();
@@ -669,20 +672,22 @@ __global__ __launch_bounds__(NTF) void k_finish_scan(KArgs a) {
     if (chunk == gridDim.x - 1 && tid == 0) a.res->groups = (s_pre + tot) & 0xFFFFFFFFull;
 }
 
-// step 2 (one workgroup): totals from the region cursors, self-circle entries resolved to global group
-// indices, the block's last group (quirk Q1 bookkeeping happens on the host), run totals advanced.
+// step 2 (a few workgroups; all compute the same totals from the region cursors, workgroup 0 publishes them):
+// self-circle entries resolved to global group indices, the block's last group (quirk Q1 bookkeeping happens
+// on the host).  The run totals advance in k_run_advance, after every reader of the old values.
+constexpr int kFinishGrid = 16;
 __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
     const int tid = threadIdx.x;
     BlockResult* r = a.res;
-    // totals and per-region sizes from the region cursors
     __shared__ uint64_t s_scpre[kMaxRegions + 1];
+    __shared__ uint32_t s_err;
     if (tid == 0) {
         uint64_t pb = 0, em = 0, sb = 0, sc = 0;
         uint32_t err = 0;
         for (int q = 0; q < a.nregions; ++q) {
             const uint64_t ca = a.cur[q].a, cb = a.cur[q].b;
             const uint64_t p = ca & kLow40, e = ca >> 40, sm = cb & kLow40, c = cb >> 40;
-            r->rpair[q] = p; r->rsam[q] = sm;
+            if (blockIdx.x == 0) { r->rpair[q] = p; r->rsam[q] = sm; }
             s_scpre[q] = sc;
             pb += p; em += e; sb += sm; sc += c;
             if (!a.ordered) {
@@ -692,31 +697,33 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
             }
         }
         s_scpre[a.nregions] = sc;
-        r->pair_bytes = pb; r->emitted = em; r->sam_bytes = sb; r->sc = sc; r->nregions = (uint32_t)a.nregions;
         if (a.ordered) { if (pb > a.out.pairs_cap) err |= E_PAIRS_CAP; if (sb > a.out.sam_cap) err |= E_SAM_CAP; if (sc > a.out.sc_cap) err |= E_SC_CAP; }
         if (a.run->sc + sc > a.sc_list_cap) err |= E_SC_CAP;
-        if (err) r->err |= err;
+        if (a.keys_rcap && a.run->emitted + em > a.key_list_cap) err |= E_SC_CAP;
+        s_err = err | r->err;                                     // r->err: what the tile kernels and the scan reported
+        if (blockIdx.x == 0) {
+            r->pair_bytes = pb; r->emitted = em; r->sam_bytes = sb; r->sc = sc; r->nregions = (uint32_t)a.nregions;
+            r->pad = a.defer_count ? *a.defer_count : 0u;         // tiles the lean kernel deferred
+            r->tiles = a.ntiles;
+            const int last = *a.last_tile;
+            if (last >= 0) r->last = a.tile_last[last];
+        }
     }
     __syncthreads();
-    const uint64_t n_sc = r->sc, sc_base = a.run->sc, g_base = a.run->groups;
-    if (r->err == 0) {
+    if (s_err == 0) {
         // self-circle entries (tile, ordinal) of every region -> global group indices, appended to the run's list
+        const uint64_t sc_base = a.run->sc, g_base = a.run->groups;
         for (int q = 0; q < a.nregions; ++q) {
             const uint64_t cnt = s_scpre[q + 1] - s_scpre[q];
             const uint64_t* src = a.out.sc + (uint64_t)q * (a.ordered ? 0 : a.sc_rcap);
-            for (uint64_t k = tid; k < cnt; k += NTF) {
+            for (uint64_t k = (uint64_t)blockIdx.x * NTF + tid; k < cnt; k += (uint64_t)gridDim.x * NTF) {
                 const uint64_t e = src[k];
                 a.sc_list[sc_base + s_scpre[q] + k] = g_base + (a.tile_groups[(uint32_t)(e >> 32)] & 0xFFFFFFFFull) + (uint32_t)(e & 0xFFFFFFFFu);
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        const int last = *a.last_tile;
-        if (last >= 0) r->last = a.tile_last[last];
-        r->tiles = a.ntiles;
-        if (a.keys_rcap && a.run->emitted + r->emitted > a.key_list_cap) r->err |= E_SC_CAP;
-    }
+    __syncthreads();                                              // every read of r->err above precedes this write
+    if (blockIdx.x == 0 && tid == 0 && (s_err & ~r->err)) r->err |= s_err;
 }
 
 // step 3 (extension, many workgroups): the block's raw key records -> the run's key list, at their
@@ -742,7 +749,7 @@ __global__ void k_run_advance(KArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-typedef TileCfg<MKT_LEAN_TILE, 2048, 4096, 256, 4> CfgFast;
+typedef TileCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, 256, 4> CfgFast;      // same tile index space as the lean kernel
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
 
 uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : CfgFast::TILE; }
@@ -762,7 +769,7 @@ hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s) {
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {
     const unsigned chunks = (a.ntiles + NTF - 1) / NTF;
     if (chunks) hipLaunchKernelGGL(k_finish_scan, dim3(chunks), dim3(NTF), 0, s, a);
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(NTF), 0, s, a);
+    hipLaunchKernelGGL(k_finish, dim3(kFinishGrid), dim3(NTF), 0, s, a);
     if (a.keys_rcap) hipLaunchKernelGGL(k_keys_place, dim3(256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_run_advance, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();

@@ -47,7 +47,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
         for (uint32_t i = 0; i < NLe; ++i)                     // the kernel: one lane per line, ballot
             if (mask_bit(st.m_surv, i) && i >= first_idx && fast_is_start(st, tv, G, i)) st.m_start[i >> 6] |= 1ull << (i & 63);
     if (!st.abn) for (uint32_t i = first_idx; i < end_idx; ++i) fast_group(st, tv, P, G, i);
-    if (st.abn) return false;
+    if (st.abn) { if (getenv("MKT_EMUL_DEBUG")) fprintf(stderr, "lean tile %u deferred: reason %u (NL %u)\n", t, st.abn, st.NL); return false; }
     TileSums s = {0, 0, 0, 0, 0};
     auto& g = st.u.g;
     for (uint32_t i = first_idx; i < NLe; ++i) {
@@ -85,7 +85,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     return true;
 }
 
-template <class Cfg>
+template <class Cfg, int FLCAP = (Cfg::LCAP > 255 ? 255 : Cfg::LCAP)>
 static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::vector<uint8_t>& pairs,
                        std::vector<uint8_t>& sam, std::vector<uint64_t>& sc, uint64_t group_base, BlockResult& res, bool lean = false) {
     memset(&res, 0, sizeof res);
@@ -100,7 +100,7 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
     TileSums run = {0, 0, 0, 0, 0};
     const uint32_t nt = num_tiles(n, Cfg::TILE);
     res.tiles = nt;
-    typedef FastCfg<Cfg::TILE, Cfg::HB, Cfg::HF, (Cfg::LCAP > 255 ? 255 : Cfg::LCAP)> FC;
+    typedef FastCfg<Cfg::TILE, Cfg::HB, Cfg::HF, FLCAP> FC;
     std::unique_ptr<FastState<FC>> fstp(new FastState<FC>);
     uint64_t lean_ok = 0;
     for (uint32_t t = 0; t < nt; ++t) {
@@ -171,7 +171,7 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
     pairs.resize(run.pair_bytes); sam.resize(run.sam_bytes); sc.resize(sc_base + run.sc);
 }
 
-typedef TileCfg<16384, 2048, 4096, 256, 4> CfgFast;
+typedef TileCfg<kLeanTile, kLeanHB, kLeanHF, 256, 4> CfgFast;          // the production geometry
 typedef TileCfg<256, 64, 192, 512, 4> CfgSafe;
 typedef TileCfg<1024, 128, 512, 96, 4> CfgMid;
 typedef TileCfg<2048, 16, 16, 128, 4> CfgNoHalo;
@@ -209,7 +209,7 @@ static void emul_feed(EmulShard& S, const char* text, size_t n, size_t block_byt
         case 1: emul_block<CfgSafe>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         case 2: emul_block<CfgMid>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         case 3: emul_block<CfgNoHalo>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
-        default: emul_block<CfgFast>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
+        default: emul_block<CfgFast, kLeanLCAP>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         }
         S.lean_tiles += r.pad; S.tiles += r.tiles;
         S.err |= r.err;
