@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     constexpr int NVEC = (Cfg::W + 15) / 16;
     constexpr int VPT = (NVEC + NT - 1) / NT;
     static_assert(Cfg::LCAP <= NT, "one line per thread in the sums");
-    const int tid = threadIdx.x;
+    const int tid0 = threadIdx.x;
     const Params P = a.P;
     const uint32_t n = a.n;
     __shared__ OutPtrs s_out;
@@ -396,6 +396,8 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
 
     // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
         if (tid == 0) { s_tile = t; s_out = a.out; fast_reset(st); }
         __syncthreads();
         STAMP(0);
