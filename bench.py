@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=int(os.environ.get("MKT_BENCH_PAIRS", 100_000_000)), help="read pairs per GPU")
-    ap.add_argument("--block-groups", type=int, default=1 << 20)
+    ap.add_argument("--block-groups", type=int, default=1 << 21, help="read groups per block (one kernel pass); 2^21 groups = 1.9 GB of SAM text")
     ap.add_argument("--sam", default="no", choices=["no", "yes"])
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

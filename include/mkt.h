@@ -53,7 +53,7 @@ typedef struct mkt_params {
     int32_t write_sam;         /* 0: argv[7] starts with N/n/0                 sam2pairs.cpp:47 */
     int32_t ref_threads;       /* argv[4] (>= 2): only the logged selfCircle depends on it (quirk Q2) */
     int32_t device;            /* HIP device ordinal */
-    uint64_t block_bytes;      /* bytes of SAM text per kernel pass, 0 = default (256 MiB); < 1 GiB */
+    uint64_t block_bytes;      /* bytes of SAM text per kernel pass, 0 = default (256 MiB); < 2 GiB - 64 KiB */
     int32_t tiles;             /* MKT_TILES_* */
     int32_t ordered;           /* 1: outputs in input order (deterministic bytes); 0 (default): any order, like the
                                 * reference, whose worker threads fwrite concurrently (sam2pairs.cpp:154,175) */
@@ -112,7 +112,7 @@ int mkt_submit(mkt_ctx* ctx, const char* bytes, size_t n, int last);
 int mkt_drain(mkt_ctx* ctx, mkt_out* out);
 
 /* ---- resident path: text already in HBM (bench.py, multi-GPU shards) --------------------------
- * The block must start on a QNAME-group boundary, end on a line end, be < 1 GiB and 16-byte
+ * The block must start on a QNAME-group boundary, end on a line end, be < 2 GiB - 64 KiB and 16-byte
  * aligned, and the memory must be readable up to the next multiple of 16 bytes past its end
  * (the kernels load whole 16-byte vectors); d_text must stay valid until mkt_sync.  Output bytes stay on the device (fetch them
  * with mkt_fetch_last_block) and results accumulate in the context exactly as for mkt_submit.

@@ -16,6 +16,9 @@
 
 using namespace mkt;
 
+// block offsets are 32 bit, the ordered kernels pack byte counts into 31-bit fields
+static const size_t kMaxBlock = ((size_t)1 << 31) - 65536;
+
 static thread_local std::string g_create_error;
 
 struct mkt_ctx {
@@ -109,7 +112,7 @@ static size_t ws_tiles_bytes(uint32_t ntiles) {
     size_t b = (size_t)ntiles * (3 * sizeof(uint64_t) + sizeof(TileLast) + sizeof(uint64_t) + sizeof(uint32_t));
     return (b + 127) & ~(size_t)127;
 }
-// fixed part: region cursors | 256 B of counters | up to 1024 scan words (1 GiB / 16 KiB / 1024 = 64 used)
+// fixed part: region cursors | 256 B of counters | up to 1024 scan words (one per 1024 tiles)
 static size_t ws_fixed_bytes() { return kMaxRegions * sizeof(RegionCur) + 256 + 1024 * sizeof(uint64_t); }
 static size_t ws_bytes_for(uint32_t ntiles) { return ws_tiles_bytes(ntiles) + ws_fixed_bytes() + sizeof(BlockResult); }
 static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
@@ -146,7 +149,7 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
     { const char* e = getenv("MKT_NO_LEAN"); c->no_lean = e && e[0] == '1'; }
     size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)256 << 20);
     if (bc < 4096) bc = 4096;
-    if (bc >= ((size_t)1 << 30)) bc = ((size_t)1 << 30) - 4096;
+    if (bc >= kMaxBlock) bc = kMaxBlock - 4096;
     bc = (bc + 15) & ~(size_t)15;
     c->block_cap = bc;
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(nullptr, MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); mkt_destroy(c); return e_ == hipErrorOutOfMemory ? MKT_E_NOMEM : MKT_E_HIP; } } while (0)
@@ -189,7 +192,7 @@ void mkt_destroy(mkt_ctx* c) {
 // enqueue one block: memset workspace, tile kernel (timed), finish kernel, result D2H into slot
 static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, size_t slot) {
     if (((uintptr_t)d_text & 15u) != 0) return fail(c, MKT_E_ARG, "block text must be 16-byte aligned");
-    if (n >= ((size_t)1 << 30)) return fail(c, MKT_E_ARG, "block of %zu bytes: must be < 1 GiB", n);
+    if (n >= kMaxBlock) return fail(c, MKT_E_ARG, "block of %zu bytes: must be < 2 GiB - 64 KiB", n);
     const uint32_t ntiles = num_tiles((uint32_t)n, tile_bytes(cfg));
     int rc = ensure_ws(c, ntiles);
     if (rc) return rc;
@@ -764,7 +767,7 @@ int mkt_dataset_create(mkt_ctx* c, uint64_t seed, int profile, int genome, int r
         HIPCHK(c, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (b + 1 == nb) total += tail;
-        if (total >= ((uint64_t)1 << 30)) { delete ds; return fail(c, MKT_E_ARG, "block %llu would hold %llu bytes (>= 1 GiB): lower groups_per_block", (unsigned long long)b, (unsigned long long)total); }
+        if (total >= kMaxBlock) { delete ds; return fail(c, MKT_E_ARG, "block %llu would hold %llu bytes (>= 2 GiB - 64 KiB): lower groups_per_block", (unsigned long long)b, (unsigned long long)total); }
         ds->off.push_back(cursor); ds->len.push_back(total); ds->groups.push_back(g + ((b + 1 == nb && tail_group) ? 1 : 0));
         cursor += (total + 15) & ~(uint64_t)15;
     }

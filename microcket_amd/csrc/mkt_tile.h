@@ -1,6 +1,6 @@
 // mkt_tile.h -- the per-tile algorithm of the fused sam2pairs kernel.
 //
-// A block of SAM text (< 1 GiB, starting on a QNAME-group boundary) is cut into fixed-size byte
+// A block of SAM text (< 2 GiB, starting on a QNAME-group boundary) is cut into fixed-size byte
 // tiles.  One workgroup owns one tile: it stages the tile plus a back halo and a forward halo in
 // LDS, finds the line starts, parses the six leading fields of every line in the window, decides
 // which surviving lines open a QNAME group (comparison with the previous surviving line, as
