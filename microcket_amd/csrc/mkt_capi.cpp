@@ -32,6 +32,7 @@ struct mkt_ctx {
     uint8_t* d_pairs = nullptr; size_t pairs_cap = 0;
     uint8_t* d_sam = nullptr; size_t sam_cap = 0;
     uint64_t* d_sc = nullptr; size_t sc_cap = 0;          // the run's resolved self-circle list (drained at syncs)
+    double sc_density = 0;                                // most self-circles per input byte seen between two syncs (0: nothing seen yet)
     uint64_t* d_sc_tmp = nullptr; size_t sc_tmp_cap = 0;  // per block: raw (tile, ordinal) entries, one slice per region
     // extensions (MKT_EXT_KEYS)
     KeyRec* d_keys_raw = nullptr; size_t keys_raw_cap = 0; // per block, one slice per region
@@ -312,6 +313,11 @@ static void fold_timing(mkt_ctx* c) {       // stream must be idle
 
 // stream idle: move the resolved self-circle indices of the folded blocks to the host, rewind the device list
 static int drain_sc(mkt_ctx* c) {
+    if (c->bytes_unsynced) {
+        const double d = (double)c->sc_on_device / (double)c->bytes_unsynced;
+        if (d > c->sc_density) c->sc_density = d;
+        if (c->sc_density == 0) c->sc_density = 1e-12;   // seen, none so far
+    }
     if (c->sc_on_device) {
         const size_t old = c->sc_host.size();
         c->sc_host.resize(old + (size_t)c->sc_on_device);
@@ -457,8 +463,11 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     if (c->finished) return fail(c, MKT_E_STATE, "submit after finish");
     if (!d_text && n) return fail(c, MKT_E_ARG, "null device pointer");
     HIPCHK(c, hipSetDevice(c->p.device));
-    // self-circle entries pile up on the device between syncs: at most one group per 64 input bytes is assumed
-    if (c->res_used == c->res_slots || (c->sc_cap && (c->bytes_unsynced + n) / 64 > c->sc_cap)) { int rc = mkt_sync(c); if (rc) return rc; }
+    // Self-circle entries pile up on the device between syncs.  Until a sync has shown this input's density the
+    // bound is one group per 64 input bytes; afterwards 8 x the highest density seen, at least one per 4096 bytes
+    // (k_finish still checks the real count: an overflow is an error, never a silent loss).
+    const double per_byte = c->sc_density > 0 ? (c->sc_density * 8 > 1.0 / 4096 ? c->sc_density * 8 : 1.0 / 4096) : 1.0 / 64;
+    if (c->res_used == c->res_slots || (c->sc_cap && (double)(c->bytes_unsynced + n) * per_byte > (double)c->sc_cap)) { int rc = mkt_sync(c); if (rc) return rc; }
     c->bytes_unsynced += n;
     int rc = enqueue_block(c, (const uint8_t*)d_text, n, c->cfg, c->res_used);
     if (rc) return rc;

@@ -76,6 +76,20 @@ MKT_HD uint64_t bits64(const uint64_t* m, uint32_t r) {
     const uint64_t lo = m[w];
     return sh ? ((lo >> sh) | (m[w + 1] << (64u - sh))) : lo;
 }
+MKT_HD uint32_t clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clzll((long long)x);
+#else
+    return (uint32_t)__builtin_clzll(x);
+#endif
+}
+MKT_HD uint32_t popc64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
 MKT_HD uint32_t ctz64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__ffsll((long long)v) - 1u;

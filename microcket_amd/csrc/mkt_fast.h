@@ -182,20 +182,6 @@ MKT_HD uint64_t mask_range(uint32_t w, uint32_t lo, uint32_t hi) {        // bit
     const uint64_t up = h >= 64u ? ~0ull : ((1ull << h) - 1ull);
     return up & ~((1ull << l) - 1ull);
 }
-MKT_HD uint32_t clz64(uint64_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__clzll((long long)x);
-#else
-    return (uint32_t)__builtin_clzll(x);
-#endif
-}
-MKT_HD uint32_t popc64(uint64_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (uint32_t)__popcll(x);
-#else
-    return (uint32_t)__builtin_popcountll(x);
-#endif
-}
 // 64 lines of a mask as one word: bit k = line start + k (lines past the table read as 0)
 MKT_HD uint64_t mask_win(const uint64_t* m, uint32_t start) {
     const uint32_t w = start >> 6, s = start & 63u;

@@ -234,14 +234,39 @@ template <class Cfg> MKT_HD void tile_trim(TileState<Cfg>& st) {
     }
 }
 
+// start of the line that contains block offset e (the byte after the last '\n' before e, or 0): walks back through
+// global memory 16 aligned bytes at a time (the block base is 16-byte aligned)
+MKT_HD uint32_t prev_line_start(const TextView& tv, uint32_t e) {
+    uint32_t lim = e;                                  // bytes [.., lim) are searched
+    while (lim > 0) {
+        const uint32_t b = (lim - 1u) & ~15u;
+        uint64_t w[2] = {0, 0};
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_memcpy(w, __builtin_assume_aligned(tv.g + b, 16), 16);      // readable up to the next multiple of 16 (include/mkt.h)
+#else
+        __builtin_memcpy(w, tv.g + b, tv.n - b < 16u ? tv.n - b : 16u);
+#endif
+        for (int h = 1; h >= 0; --h) {
+            const uint32_t base = b + 8u * (uint32_t)h;
+            if (base >= lim) continue;
+            const uint64_t x = w[h] ^ 0x0A0A0A0A0A0A0A0Aull;
+            uint64_t z = ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x | 0x7F7F7F7F7F7F7F7Full);   // 0x80 where byte == '\n'
+            const uint32_t keep = lim - base;          // bytes of this word below lim (1..8, or more)
+            if (keep < 8u) z &= (1ull << (8u * keep)) - 1ull;
+            if (z) return base + (63u - clz64(z)) / 8u + 1u;
+        }
+        lim = b;
+    }
+    return 0;
+}
+
 // ---- does surviving line i open a group?  (pairutil.h:163: QNAME != the previous SURVIVING line's)
 template <class Cfg> MKT_COLD bool start_vs_global(const TileState<Cfg>& st, const TextView& tv, const Params& P, uint32_t i) {
     // no surviving line precedes line i inside the window: walk back through global memory
     uint32_t q = st.off[0];
     const uint32_t qa = st.off[i] + st.qn_off[i], ql = st.qn_len[i];
     while (q > 0) {
-        uint32_t ls = q - 1;                          // the '\n' ending the previous line
-        while (ls > 0 && tv.at(ls - 1) != '\n') --ls;
+        const uint32_t ls = prev_line_start(tv, q - 1);   // q - 1: the '\n' ending the previous line
         Rec r = parse_record(tv, ls, P);
         if (r.survive && rec_in_range(r)) return !text_eq(tv, qa, ql, ls + r.qn_off, r.qn_len);
         q = ls;
