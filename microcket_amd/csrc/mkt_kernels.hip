@@ -681,13 +681,15 @@ constexpr int kFinishGrid = 16;
 __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
     const int tid = threadIdx.x;
     BlockResult* r = a.res;
-    __shared__ uint64_t s_scpre[kMaxRegions + 1];
+    __shared__ uint64_t s_scpre[kMaxRegions + 1], s_ca[kMaxRegions], s_cb[kMaxRegions];
     __shared__ uint32_t s_err;
+    if (tid < a.nregions) { s_ca[tid] = a.cur[tid].a; s_cb[tid] = a.cur[tid].b; }      // one lane per region: the loads overlap
+    __syncthreads();
     if (tid == 0) {
         uint64_t pb = 0, em = 0, sb = 0, sc = 0;
         uint32_t err = 0;
         for (int q = 0; q < a.nregions; ++q) {
-            const uint64_t ca = a.cur[q].a, cb = a.cur[q].b;
+            const uint64_t ca = s_ca[q], cb = s_cb[q];
             const uint64_t p = ca & kLow40, e = ca >> 40, sm = cb & kLow40, c = cb >> 40;
             if (blockIdx.x == 0) { r->rpair[q] = p; r->rsam[q] = sm; }
             s_scpre[q] = sc;

@@ -267,8 +267,24 @@ template <class Cfg> MKT_COLD bool start_vs_global(const TileState<Cfg>& st, con
     const uint32_t qa = st.off[i] + st.qn_off[i], ql = st.qn_len[i];
     while (q > 0) {
         const uint32_t ls = prev_line_start(tv, q - 1);   // q - 1: the '\n' ending the previous line
-        Rec r = parse_record(tv, ls, P);
-        if (r.survive && rec_in_range(r)) return !text_eq(tv, qa, ql, ls + r.qn_off, r.qn_len);
+        // the line's head comes over in eleven independent 16-byte loads and is parsed from that private copy
+        // (the byte-at-a-time parser on global memory is a chain of dependent loads)
+        alignas(16) uint8_t head[176];
+        TextView hv = tv;
+        hv.win = head; hv.w0 = ls & ~15u;
+        hv.wlen = tv.n - hv.w0 < 176u ? tv.n - hv.w0 : 176u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        for (uint32_t k = 0; k < 176u; k += 16u)
+            if (hv.w0 + k < tv.n) __builtin_memcpy(head + k, __builtin_assume_aligned(tv.g + hv.w0 + k, 16), 16);
+#else
+        __builtin_memcpy(head, tv.g + hv.w0, hv.wlen);
+#endif
+        Rec r = parse_record(hv, ls, P);
+        if (r.survive && rec_in_range(r)) {
+            if (r.qn_len != ql) return true;
+            for (uint32_t k = 0; k < ql; ++k) if (tv.at(qa + k) != hv.at(ls + r.qn_off + k)) return true;
+            return false;
+        }
         q = ls;
     }
     return true;                                      // first surviving line of the block
