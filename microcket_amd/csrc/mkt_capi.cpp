@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <string>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "../../include/mkt.h"
@@ -32,6 +33,7 @@ struct mkt_ctx {
     uint8_t* d_pairs = nullptr; size_t pairs_cap = 0;
     uint8_t* d_sam = nullptr; size_t sam_cap = 0;
     uint64_t* d_sc = nullptr; size_t sc_cap = 0;          // the run's resolved self-circle list (drained at syncs)
+    unsigned long long* d_sc_logged = nullptr;            // result word of k_sc_logged
     double sc_density = 0;                                // most self-circles per input byte seen between two syncs (0: nothing seen yet)
     uint64_t* d_sc_tmp = nullptr; size_t sc_tmp_cap = 0;  // per block: raw (tile, ordinal) entries, one slice per region
     // extensions (MKT_EXT_KEYS)
@@ -47,12 +49,11 @@ struct mkt_ctx {
     // streaming outputs
     std::vector<char> out_pairs, out_sam, tail_pairs, tail_sam, drained_pairs, drained_sam;
     RunAccum acc;
-    std::vector<uint64_t> sc_host;
     bool input_done = false, finished = false;
     uint64_t bytes_in = 0, blocks = 0;
     size_t last_n = 0;                   // bytes of the last resident block
     uint64_t keys_upper = 0;             // upper bound of the key records enqueued so far (extension)
-    uint64_t sc_on_device = 0;           // self-circle entries of folded blocks still in d_sc
+    uint64_t sc_unfolded = 0;            // self-circle entries of the blocks folded at the last sync (for the density estimate)
     uint64_t bytes_unsynced = 0;         // resident bytes enqueued since the last sync
     // timing
     std::vector<hipEvent_t> ev;          // start/stop pairs of the tile kernel
@@ -185,9 +186,12 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_syn_sizes) (void)hipFree(c->d_syn_sizes);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->d_sc_logged) (void)hipFree(c->d_sc_logged);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+static int ensure_sc_list(mkt_ctx* c, size_t need);
 
 // ---------------------------------------------------------------------------------------------
 // enqueue one block: memset workspace, tile kernel (timed), finish kernel, result D2H into slot
@@ -201,11 +205,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     // checked in-kernel and grown on demand (the result carries the exact size)
     if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, n / 3 + 65536))) return rc;
     if (c->P.write_sam && (rc = ensure_dev(c, &c->d_sam, &c->sam_cap, n + n / 4 + 65536))) return rc;
-    if (!c->d_sc) {
-        size_t need = (size_t)1 << 25;          // 32 Mi self-circle indices between two drains (256 MiB)
-        HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
-        c->sc_cap = need;
-    }
+    if (!c->d_sc && (rc = ensure_sc_list(c, 1))) return rc;
     KArgs a;
     memset(&a, 0, sizeof a);
     uint8_t* w = c->d_ws;
@@ -311,22 +311,36 @@ static void fold_timing(mkt_ctx* c) {       // stream must be idle
     c->ev.clear(); c->ev_bytes.clear();
 }
 
-// stream idle: move the resolved self-circle indices of the folded blocks to the host, rewind the device list
-static int drain_sc(mkt_ctx* c) {
+// The run's resolved self-circle indices stay on the device until the end of the input (k_sc_logged).
+// Stream idle: make room for `need` entries, keeping the c->acc.sc entries already there.
+static int ensure_sc_list(mkt_ctx* c, size_t need) {
+    if (need <= c->sc_cap) return MKT_OK;
+    size_t ncap = c->sc_cap ? c->sc_cap : ((size_t)1 << 25);       // 32 Mi entries (256 MiB) to start with
+    while (ncap < need) ncap *= 2;
+    uint64_t* nl = nullptr;
+    HIPCHK(c, hipMalloc((void**)&nl, ncap * sizeof(uint64_t)));
+    if (c->d_sc) {
+        if (c->acc.sc) HIPCHK(c, hipMemcpy(nl, c->d_sc, (size_t)c->acc.sc * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+        HIPCHK(c, hipFree(c->d_sc));
+    }
+    c->d_sc = nl; c->sc_cap = ncap;
+    return MKT_OK;
+}
+// after a sync: what this input's self-circle density looks like (entries per input byte, highest seen)
+static void note_sc_density(mkt_ctx* c) {
     if (c->bytes_unsynced) {
-        const double d = (double)c->sc_on_device / (double)c->bytes_unsynced;
+        const double d = (double)c->sc_unfolded / (double)c->bytes_unsynced;
         if (d > c->sc_density) c->sc_density = d;
         if (c->sc_density == 0) c->sc_density = 1e-12;   // seen, none so far
     }
-    if (c->sc_on_device) {
-        const size_t old = c->sc_host.size();
-        c->sc_host.resize(old + (size_t)c->sc_on_device);
-        HIPCHK(c, hipMemcpy(c->sc_host.data() + old, c->d_sc, (size_t)c->sc_on_device * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        c->sc_on_device = 0;
-    }
-    if (c->d_run) HIPCHK(c, hipMemsetAsync(&c->d_run->sc, 0, sizeof(uint64_t), c->stream));
-    c->bytes_unsynced = 0;
-    return MKT_OK;
+    c->sc_unfolded = 0; c->bytes_unsynced = 0;
+}
+// entries the next `bytes` of input may add at most, as far as the host can tell: one group per 64 bytes until a sync
+// has shown this input's density, afterwards 4 x the highest density seen and at least one per 65536 bytes.  k_finish
+// checks the real count against the capacity: a wrong guess is an error (E_SC_CAP), never a silent loss.
+static size_t sc_estimate(const mkt_ctx* c, size_t bytes) {
+    const double per_byte = c->sc_density > 0 ? (c->sc_density * 4 > 1.0 / 65536 ? c->sc_density * 4 : 1.0 / 65536) : 1.0 / 64;
+    return (size_t)((double)bytes * per_byte) + 4096;
 }
 
 static int check_result(mkt_ctx* c, const BlockResult& r) {
@@ -345,6 +359,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     HIPCHK(c, hipMemcpyAsync(c->d_in, c->h_in, n, hipMemcpyHostToDevice, c->stream));
     int cfg = c->cfg;
     BlockResult r;
+    if ((rc = ensure_sc_list(c, (size_t)c->acc.sc + n / 64 + 4096))) return rc;      // at most one group per 64 input bytes
     for (int attempt = 0;; ++attempt) {
         if ((rc = enqueue_block(c, c->d_in, n, cfg, 0))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -363,18 +378,13 @@ static int run_host_block(mkt_ctx* c, size_t n) {
             uint64_t mx = 0; for (uint32_t q = 0; q < nr; ++q) if (r.rsam[q] > mx) mx = r.rsam[q];
             if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc; grew = true;
         }
-        if (r.err & E_SC_CAP) {            // per-block raw entries: grow the slices; the run's list is drained after every host block
+        if (r.err & E_SC_CAP) {            // per-block raw entries: grow the slices, and the run's list with them
             size_t need = (size_t)r.sc * 4 + 65536;
             if (c->d_sc_tmp) HIPCHK(c, hipFree(c->d_sc_tmp));
             c->d_sc_tmp = nullptr; c->sc_tmp_cap = 0;
             HIPCHK(c, hipMalloc((void**)&c->d_sc_tmp, need * kMaxRegions * sizeof(uint64_t)));
             c->sc_tmp_cap = need * kMaxRegions;
-            if (c->sc_cap < need) {
-                HIPCHK(c, hipFree(c->d_sc));
-                c->d_sc = nullptr; c->sc_cap = 0;
-                HIPCHK(c, hipMalloc((void**)&c->d_sc, need * sizeof(uint64_t)));
-                c->sc_cap = need;
-            }
+            if ((rc = ensure_sc_list(c, (size_t)c->acc.sc + need))) return rc;
             grew = true;
         }
         if (!grew) return check_result(c, r);
@@ -382,8 +392,8 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     // fetch outputs
     c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
     ++c->blocks;
-    c->sc_on_device += r.sc;
-    if ((rc = drain_sc(c))) return rc;
+    c->sc_unfolded += r.sc; c->bytes_unsynced += n;
+    note_sc_density(c);
     size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
     if (c->h_stage.size() < pb + sb) c->h_stage.resize(pb + sb);
     // gather the region slices: .pairs regions first, then .sam regions; remember where each region landed
@@ -463,11 +473,15 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     if (c->finished) return fail(c, MKT_E_STATE, "submit after finish");
     if (!d_text && n) return fail(c, MKT_E_ARG, "null device pointer");
     HIPCHK(c, hipSetDevice(c->p.device));
-    // Self-circle entries pile up on the device between syncs.  Until a sync has shown this input's density the
-    // bound is one group per 64 input bytes; afterwards 8 x the highest density seen, at least one per 4096 bytes
-    // (k_finish still checks the real count: an overflow is an error, never a silent loss).
-    const double per_byte = c->sc_density > 0 ? (c->sc_density * 8 > 1.0 / 4096 ? c->sc_density * 8 : 1.0 / 4096) : 1.0 / 64;
-    if (c->res_used == c->res_slots || (c->sc_cap && (double)(c->bytes_unsynced + n) * per_byte > (double)c->sc_cap)) { int rc = mkt_sync(c); if (rc) return rc; }
+    // The self-circle list must have room for what the blocks in flight may add (their counts are known at the next sync)
+    if (c->res_used == c->res_slots || (size_t)c->acc.sc + sc_estimate(c, c->bytes_unsynced + n) > c->sc_cap) {
+        if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "submit_device: sync before block (slots %zu/%zu, unsynced %.1f GB, density %.3g /B, list %llu of %zu)\n",
+                                              c->res_used, c->res_slots, (double)c->bytes_unsynced / 1e9, c->sc_density, (unsigned long long)c->acc.sc, c->sc_cap);
+        int rc = mkt_sync(c);
+        if (rc) return rc;
+        // room for as much again as the run holds now, and for this block at the very least
+        if ((rc = ensure_sc_list(c, 2 * (size_t)c->acc.sc + sc_estimate(c, n)))) return rc;
+    }
     c->bytes_unsynced += n;
     int rc = enqueue_block(c, (const uint8_t*)d_text, n, c->cfg, c->res_used);
     if (rc) return rc;
@@ -480,18 +494,25 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
 int mkt_sync(mkt_ctx* c) {
     if (!c) return MKT_E_ARG;
     HIPCHK(c, hipSetDevice(c->p.device));
+    const bool dbg = getenv("MKT_DEBUG_SYNC") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = dbg ? now() : 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    const double t1 = dbg ? now() : 0;
     fold_timing(c);
+    const double t2 = dbg ? now() : 0;
     int rc = MKT_OK;
     for (size_t k = c->res_folded; k < c->res_used; ++k) {
         const BlockResult& r = c->h_res[k];
         if (r.err) { rc = check_result(c, r); break; }      // resident blocks are not retried: fail loudly
         c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
-        c->sc_on_device += r.sc;
+        c->sc_unfolded += r.sc;
         ++c->blocks;
     }
+    const size_t nres = c->res_used;
     c->res_used = 0; c->res_folded = 0;
-    if (rc == MKT_OK) rc = drain_sc(c);
+    if (rc == MKT_OK) note_sc_density(c);
+    if (dbg) fprintf(stderr, "mkt_sync: %zu blocks, wait %.2f ms, timing fold %.2f ms, results %.2f ms\n", nres, t1 - t0, t2 - t1, now() - t2);
     return rc;
 }
 
@@ -525,9 +546,17 @@ int mkt_finish(mkt_ctx* c, int drop_last, uint64_t group_offset, uint64_t total_
     if (!c || !st) return MKT_E_ARG;
     int rc = mkt_sync(c);
     if (rc) return rc;
-    if (c->sc_host.size() != c->acc.sc) return fail(c, MKT_E_STATE, "self-circle list out of step (%zu vs %llu)", c->sc_host.size(), (unsigned long long)c->acc.sc);
     const uint64_t K = total_groups ? total_groups : c->acc.groups;
-    RunStats s = c->acc.finish(drop_last != 0, (uint32_t)c->p.ref_threads, group_offset, K, c->sc_host.data());
+    unsigned long long logged = 0;
+    if (c->acc.sc) {
+        if (!c->d_sc_logged) HIPCHK(c, hipMalloc((void**)&c->d_sc_logged, sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_sc_logged, 0, sizeof(unsigned long long), c->stream));
+        const uint64_t drop_group = c->acc.drops(drop_last != 0) ? c->acc.groups - 1 : ~0ull;
+        HIPCHK(c, launch_sc_logged(c->d_sc, c->acc.sc, drop_group, group_offset, K, (uint32_t)c->p.ref_threads, c->d_sc_logged, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&logged, c->d_sc_logged, sizeof logged, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    RunStats s = c->acc.finish_logged(drop_last != 0, logged);
     memset(st, 0, sizeof *st);
     st->lowMap = s.counters[C_LOWMAP]; st->manyHits = s.counters[C_MANYHITS]; st->unpaired = s.counters[C_UNPAIRED];
     st->selfCircle = s.counters[C_SELFCIRCLE]; st->trans = s.counters[C_TRANS];
@@ -680,7 +709,7 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
-    c->sc_host.clear(); c->sc_on_device = 0; c->bytes_unsynced = 0; c->keys_upper = 0;
+    c->sc_unfolded = 0; c->bytes_unsynced = 0; c->keys_upper = 0;
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;

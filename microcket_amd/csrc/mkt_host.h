@@ -47,31 +47,34 @@ struct RunAccum {
         groups += r.groups; emitted += r.emitted; pair_bytes += r.pair_bytes; sam_bytes += r.sam_bytes;
         if (r.last.valid) pending = r.last;
     }
-    // drop_last: this shard holds the input's last group (Q1).  group_offset / K_total place the
-    // shard in the whole input (single process: 0 and `groups`).
-    // sc_idx: shard-local indices of the self-circle groups (`sc` entries, any order).
-    RunStats finish(bool drop_last, uint32_t ref_threads, uint64_t group_offset, uint64_t K_total, const uint64_t* sc_idx) const {
+    // drop_last: this shard holds the input's last group (Q1).
+    bool drops(bool drop_last) const { return drop_last && pending.valid; }
+    // `logged`: how many of the run's self-circle groups reach the .log (quirk Q2), the dropped last group excluded
+    RunStats finish_logged(bool drop_last, uint64_t logged) const {
         RunStats s;
         memset(&s, 0, sizeof s);
         uint64_t c[C_COUNT];
         for (int k = 0; k < (int)C_COUNT; ++k) c[k] = counters[k];
-        uint64_t n_sc = sc;
         s.pairs = emitted; s.pair_bytes = pair_bytes; s.sam_bytes = sam_bytes;
-        if (drop_last && pending.valid) {
+        if (drops(drop_last)) {
             if (pending.counter) --c[pending.counter];
             if (pending.pair_bytes) { --s.pairs; s.pair_bytes -= pending.pair_bytes; s.sam_bytes -= pending.sam_bytes; }
-        }
-        uint64_t logged = 0;
-        const bool drop = drop_last && pending.valid;
-        for (uint64_t k = 0; k < n_sc; ++k) {
-            if (drop && sc_idx[k] + 1 == groups) continue;             // the dropped last group
-            if (selfcircle_logged(group_offset + sc_idx[k], K_total, ref_threads)) ++logged;
         }
         for (int k = 0; k < (int)C_COUNT; ++k) s.counters[k] = (uint32_t)c[k];     // u32 wrap as the reference's kstat
         s.selfcircle_all = (uint32_t)c[C_SELFCIRCLE];
         s.counters[C_SELFCIRCLE] = (uint32_t)logged;
         s.groups = groups;
         return s;
+    }
+    // The same from a host-side list.  group_offset / K_total place the shard in the whole input (single process:
+    // 0 and `groups`); sc_idx: shard-local indices of the self-circle groups (`sc` entries, any order).
+    RunStats finish(bool drop_last, uint32_t ref_threads, uint64_t group_offset, uint64_t K_total, const uint64_t* sc_idx) const {
+        uint64_t logged = 0;
+        for (uint64_t k = 0; k < sc; ++k) {
+            if (drops(drop_last) && sc_idx[k] + 1 == groups) continue;             // the dropped last group
+            if (selfcircle_logged(group_offset + sc_idx[k], K_total, ref_threads)) ++logged;
+        }
+        return finish_logged(drop_last, logged);
     }
 };
 

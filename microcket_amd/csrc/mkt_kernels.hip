@@ -752,6 +752,27 @@ __global__ void k_run_advance(KArgs a) {
     if (threadIdx.x == 0 && r->err == 0) { a.run->groups += r->groups; a.run->sc += r->sc; a.run->emitted += r->emitted; }     // a failed block is re-run
 }
 
+// End of the input: how many of the run's self-circle groups the reference would have LOGGED (quirk Q2: only its
+// thread 0's share of every batch reaches the .log).  The list never leaves the device.
+__global__ void k_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_group, uint64_t group_offset, uint64_t K_total, uint32_t ref_threads,
+                            unsigned long long* out) {
+    unsigned long long mine = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t g = list[k];
+        if (g == drop_group) continue;                                  // the dropped last group (quirk Q1)
+        if (selfcircle_logged(group_offset + g, K_total, ref_threads)) ++mine;
+    }
+    for (int d = 32; d >= 1; d >>= 1) mine += shfl_xor64(mine, d);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_group, uint64_t group_offset, uint64_t K_total, uint32_t ref_threads,
+                            unsigned long long* out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(k_sc_logged, dim3(grid), dim3(256), 0, s, list, n, drop_group, group_offset, K_total, ref_threads, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 typedef TileCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, 256, 4> CfgFast;      // same tile index space as the lean kernel
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;

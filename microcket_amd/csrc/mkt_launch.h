@@ -57,6 +57,8 @@ hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s);
 uint32_t fast_tile_bytes();
 uint32_t finish_chunk_tiles();
 hipError_t launch_finish(const KArgs& a, hipStream_t s);
+hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_group, uint64_t group_offset, uint64_t K_total, uint32_t ref_threads,
+                            unsigned long long* out, hipStream_t s);
 
 // extensions (duplicate marking, per-chromosome counts) over the run's key list
 struct DedupResult { uint64_t total, dups; };
