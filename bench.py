@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=int(os.environ.get("MKT_BENCH_PAIRS", 100_000_000)), help="read pairs per GPU")
     ap.add_argument("--block-groups", type=int, default=1 << 21, help="read groups per block (one kernel pass); 2^21 groups = 1.9 GB of SAM text")
     ap.add_argument("--sam", default="no", choices=["no", "yes"])
+    ap.add_argument("--read-len", type=int, default=150, help="read length of the synthetic data (BASELINE config: 150)")
+    ap.add_argument("--tiles", default="fast", choices=["fast", "auto"], help="tile geometry: the 32 KB lean tiles, or chosen per input")
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
@@ -129,9 +131,9 @@ def main():
 
     profile = 0 if args.mode == "unc" else 1
     seed = 20260104 + 1  # seeds 20260104 + config index
-    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=m.TILES_FAST)
+    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=m.TILES_FAST if args.tiles == "fast" else m.TILES_AUTO)
     t0 = time.time()
-    ds = ctx.dataset(seed, profile, args.pairs, args.block_groups, first_group=rank * args.pairs, genome=0, read_len=150, lanes=1,
+    ds = ctx.dataset(seed, profile, args.pairs, args.block_groups, first_group=rank * args.pairs, genome=0, read_len=args.read_len, lanes=1,
                      tail_group=(rank == world - 1))
     log(f"[rank {rank}] data set: {ds.total_groups} pairs, {ds.total_bytes / 1e9:.2f} GB in {ds.n_blocks} blocks, generated in {time.time() - t0:.1f} s")
 
@@ -204,7 +206,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {args.pairs} synthetic 150 bp PE read pairs per GPU, hg38 chromosome names, {args.mode} mode, sam={args.sam}, "
+                "workload": f"C2: {args.pairs} synthetic {args.read_len} bp PE read pairs per GPU, hg38 chromosome names, {args.mode} mode, sam={args.sam}, "
                             f"seed {seed}, one step = one pass over the whole resident data set",
                 "pairs_per_gpu": ds.total_groups,
                 "sam_bytes_per_gpu": ds.total_bytes,

@@ -26,6 +26,7 @@ struct mkt_ctx {
     mkt_params p;
     Params P;
     int cfg = CFG_FAST;
+    int last_cfg = CFG_FAST;            // geometry of the newest resident block (mkt_fetch_last_block)
     hipStream_t stream = nullptr;
     size_t block_cap = 0;
     // device
@@ -193,6 +194,12 @@ void mkt_destroy(mkt_ctx* c) {
 
 static int ensure_sc_list(mkt_ctx* c, size_t need);
 
+// MKT_TILES_AUTO: when the 32 KB lean kernel leaves more than one tile in eight to the generic kernel (short lines
+// overflow its line table), the following blocks use the 16 KB geometry
+static void adapt_geometry(mkt_ctx* c, const BlockResult& r) {
+    if (c->p.tiles == MKT_TILES_AUTO && c->cfg == CFG_FAST && !c->p.ordered && r.tiles >= 8 && (uint64_t)r.pad * 8 > r.tiles) c->cfg = CFG_DENSE;
+}
+
 // ---------------------------------------------------------------------------------------------
 // enqueue one block: memset workspace, tile kernel (timed), finish kernel, result D2H into slot
 static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, size_t slot) {
@@ -284,11 +291,11 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     HIPCHK(c, hipEventCreate(&e1));
     c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
     int grid = (int)(ntiles < 1024u ? ntiles : 1024u);
-    const bool lean = !c->p.ordered && cfg == CFG_FAST && !c->no_lean;
+    const bool lean = !c->p.ordered && cfg != CFG_SMALL && !c->no_lean;
     HIPCHK(c, hipEventRecord(e0, c->stream));
     if (lean) {
         // lean kernel over all tiles, then the generic kernel over the tiles it deferred
-        HIPCHK(c, launch_fast(a, grid, c->stream));
+        HIPCHK(c, launch_fast(a, cfg, grid, c->stream));
         HIPCHK(c, hipEventRecord(e1, c->stream));
         KArgs b = a;
         b.use_list = 1; b.ticket = ticket2;
@@ -367,7 +374,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         r = c->h_res[0];
         if (r.err == 0) break;
         if (attempt >= 3) return check_result(c, r);
-        if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg == CFG_FAST && c->p.tiles == MKT_TILES_AUTO) { cfg = CFG_SMALL; continue; }
+        if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg != CFG_SMALL && c->p.tiles == MKT_TILES_AUTO) { cfg = cfg == CFG_FAST ? CFG_DENSE : CFG_SMALL; continue; }
         bool grew = false;
         const uint32_t nr = r.nregions ? r.nregions : 1;
         if (r.err & E_PAIRS_CAP) {
@@ -390,7 +397,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         if (!grew) return check_result(c, r);
     }
     // fetch outputs
-    c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
+    c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad; adapt_geometry(c, r);
     ++c->blocks;
     c->sc_unfolded += r.sc; c->bytes_unsynced += n;
     note_sc_density(c);
@@ -474,7 +481,10 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     if (!d_text && n) return fail(c, MKT_E_ARG, "null device pointer");
     HIPCHK(c, hipSetDevice(c->p.device));
     // The self-circle list must have room for what the blocks in flight may add (their counts are known at the next sync)
-    if (c->res_used == c->res_slots || (size_t)c->acc.sc + sc_estimate(c, c->bytes_unsynced + n) > c->sc_cap) {
+    // ... and the first block of an input is a probe: its result (self-circle density, tiles the lean kernel could not
+    // take) is looked at before the second block is queued
+    const bool probe = c->sc_density == 0 && c->res_used == 1;
+    if (probe || c->res_used == c->res_slots || (size_t)c->acc.sc + sc_estimate(c, c->bytes_unsynced + n) > c->sc_cap) {
         if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "submit_device: sync before block (slots %zu/%zu, unsynced %.1f GB, density %.3g /B, list %llu of %zu)\n",
                                               c->res_used, c->res_slots, (double)c->bytes_unsynced / 1e9, c->sc_density, (unsigned long long)c->acc.sc, c->sc_cap);
         int rc = mkt_sync(c);
@@ -483,10 +493,11 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
         if ((rc = ensure_sc_list(c, 2 * (size_t)c->acc.sc + sc_estimate(c, n)))) return rc;
     }
     c->bytes_unsynced += n;
-    int rc = enqueue_block(c, (const uint8_t*)d_text, n, c->cfg, c->res_used);
+    const int cfg_used = c->cfg;
+    int rc = enqueue_block(c, (const uint8_t*)d_text, n, cfg_used, c->res_used);
     if (rc) return rc;
     ++c->res_used;
-    c->last_n = n;
+    c->last_n = n; c->last_cfg = cfg_used;
     c->bytes_in += n;
     return MKT_OK;
 }
@@ -505,7 +516,7 @@ int mkt_sync(mkt_ctx* c) {
     for (size_t k = c->res_folded; k < c->res_used; ++k) {
         const BlockResult& r = c->h_res[k];
         if (r.err) { rc = check_result(c, r); break; }      // resident blocks are not retried: fail loudly
-        c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
+        c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad; adapt_geometry(c, r);
         c->sc_unfolded += r.sc;
         ++c->blocks;
     }
@@ -522,7 +533,7 @@ int mkt_fetch_last_block(mkt_ctx* c, char* pairs, size_t pairs_cap, size_t* pair
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the last folded result is not kept per block; re-read it from the device workspace
     BlockResult r;
-    const uint32_t ntiles = num_tiles((uint32_t)c->last_n, tile_bytes(c->cfg));
+    const uint32_t ntiles = num_tiles((uint32_t)c->last_n, tile_bytes(c->last_cfg));
     const uint8_t* w = c->d_ws + ws_tiles_bytes(ntiles) + ws_fixed_bytes();
     HIPCHK(c, hipMemcpy(&r, w, sizeof r, hipMemcpyDeviceToHost));
     if (pairs_len) *pairs_len = (size_t)r.pair_bytes;
@@ -710,6 +721,7 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
     c->sc_unfolded = 0; c->bytes_unsynced = 0; c->keys_upper = 0;
+    c->sc_density = 0; c->cfg = c->p.tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;      // a new input is probed afresh
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;

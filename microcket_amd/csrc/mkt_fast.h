@@ -22,6 +22,9 @@ namespace mkt {
 
 // geometry of the production lean kernel (also what tests/host/tile_emul.cpp emulates as config 0 / 10)
 constexpr int kLeanTile = 32768, kLeanHB = 2048, kLeanHF = 3072, kLeanLCAP = 160;
+// ... and of its variant for short lines (reads of 50-75 bp: ~200-byte lines would overflow the 160-line table of a
+// 37 KB window); the host switches to it when the first blocks leave too many tiles to the generic kernel
+constexpr int kDenseTile = 16384, kDenseHB = 1024, kDenseHF = 2048, kDenseLCAP = 160;
 
 template <int TILE_, int HB_, int HF_, int LCAP_>
 struct FastCfg {

@@ -775,20 +775,23 @@ hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_grou
 
 // ---------------------------------------------------------------------------------------------
 typedef TileCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, 256, 4> CfgFast;      // same tile index space as the lean kernel
+typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;             // ... and as its short-line variant
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
+typedef FastCfg<kDenseTile, kDenseHB, kDenseHF, kDenseLCAP> CfgLeanDense;
 
-uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : CfgFast::TILE; }
+uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : (cfg == CFG_DENSE ? CfgDense::TILE : CfgFast::TILE); }
 
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
     if (cfg == CFG_SMALL) hipLaunchKernelGGL(k_tiles<CfgSmall>, dim3(grid), dim3(NT), 0, s, a);
+    else if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_tiles<CfgDense>, dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(k_tiles<CfgFast>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
-uint32_t fast_tile_bytes() { return CfgLean::TILE; }
-hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s) {
+hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_fast<CfgLean>, dim3(grid), dim3(NT), 0, s, a);
+    if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_fast<CfgLeanDense>, dim3(grid), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL(k_fast<CfgLean>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {

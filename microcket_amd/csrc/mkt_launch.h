@@ -7,7 +7,7 @@
 
 namespace mkt {
 
-enum { CFG_FAST = 0, CFG_SMALL = 1 };
+enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2 };      // tile geometries: 32 KB lean, 256 B generic only, 16 KB lean (short lines)
 
 // totals of the blocks a context has finished, kept on the device so that resident blocks chain
 // without a host round trip
@@ -53,8 +53,7 @@ struct KArgs {
 
 uint32_t tile_bytes(int cfg);
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s);
-hipError_t launch_fast(const KArgs& a, int grid, hipStream_t s);
-uint32_t fast_tile_bytes();
+hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s);
 uint32_t finish_chunk_tiles();
 hipError_t launch_finish(const KArgs& a, hipStream_t s);
 hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_group, uint64_t group_offset, uint64_t K_total, uint32_t ref_threads,

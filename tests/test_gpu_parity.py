@@ -148,10 +148,14 @@ def test_resident_path_multi_block_and_q2_across_batches():
             for (p, nb, g) in ds.blocks:
                 c.submit_device(p, nb)
             st = c.finish(True)
+            tm = c.timing()
             ds.close()
         po, so, lo, ost = util.oracle_run(host, "unc", T, 0.5, 0, False)
         assert c.format_log(st) == lo, (T, c.format_log(st), lo)
         assert st.groups == ost.groups and st.pairs == ost.pairs
+        # 50 bp reads: ~190-byte lines overflow the 160-line table of the 32 KB lean tiles, so the first block goes to
+        # the generic kernel tile by tile; MKT_TILES_AUTO then moves to the 16 KB geometry and the rest stays lean
+        assert 0 < tm.deferred_tiles < tm.tiles // 3, (tm.tiles, tm.deferred_tiles)
 
 
 def test_two_contexts_as_two_shards():
