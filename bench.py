@@ -189,6 +189,21 @@ def main():
     result = None
     if rank == 0:
         achieved = (algo_bytes_step * args.steps) / (tm_ms / 1e3) / 1e9 if tm_ms > 0 else 0.0
+        # HBM traffic of k_fast per launch: rocprofv3 cannot run inside this process, so the figure comes from the committed
+        # PMC passes of this same command (tools/round_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE
+        # doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane streams), as measured traffic / algorithmic bytes,
+        # applied to this run's algorithmic bytes per launch.  Only for the profiled workload shape; otherwise null.
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if cands and tm_launch and args.read_len == 150 and args.sam == "no" and args.mode == "unc":
+                tj = json.loads(open(cands[-1]).read())
+                if tj.get("block_groups") == args.block_groups:
+                    traffic = tj["traffic_over_algorithmic"] * algo_bytes_step * args.steps / tm_launch
+                    traffic_src = f"profiles/{os.path.basename(cands[-1])}: traffic/algorithmic = {tj['traffic_over_algorithmic']:.3f} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        except Exception:
+            traffic, traffic_src = None, None
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(ctx, ds, args.cpu_sample_pairs, 8)
@@ -223,7 +238,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src,
                 "launches": tm_launch,
                 "avg_launch_ms": tm_ms / tm_launch if tm_launch else None,
                 "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / tm_launch if tm_launch else None,
