@@ -33,11 +33,12 @@ struct FastCfg {
     static constexpr int GCAP = 96;                  // emitting groups per tile (more: generic kernel)
     static constexpr int NV16 = (W + 15) / 16 + 8;   // 16-byte vectors of the window (+ padding)
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
-    static constexpr int HW = LCAP_ * HEADB;         // bytes of the head store
+    static constexpr int HSTRIDE = HEADB + 4;        // row pitch: 33 dwords, so lanes reading the same column of their own rows hit 32 different banks
+    static constexpr int HW = LCAP_ * HSTRIDE;       // bytes of the head store
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
-    static_assert(LCAP_ * 128 < 65536, "head-store offsets are 16 bit");
+    static_assert(LCAP_ * 132 < 65536, "head-store offsets are 16 bit");
 };
 
 // why a tile is left to the generic kernel (low byte of FastState::abn; any value != 0 defers)
@@ -47,11 +48,11 @@ constexpr uint8_t LB_EMIT = 8;          // line belongs to an emitting group (it
 
 template <class Cfg>
 struct FastState {
-    alignas(16) uint8_t win[Cfg::HW + 16];           // line heads, HEADB bytes per line
+    alignas(16) uint8_t win[Cfg::HW + 16];           // line heads, HEADB bytes per line, rows HSTRIDE apart
     // per line of the window
     uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP];
     uint32_t right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP];
-    uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HEADB + (goff & 15)
+    uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HSTRIDE + (goff & 15)
     uint16_t goff[Cfg::LCAP];            // line start, window relative
     uint16_t flag[Cfg::LCAP];
     uint8_t qn_off[Cfg::LCAP], qn_len[Cfg::LCAP], rn_off[Cfg::LCAP], rn_len[Cfg::LCAP], segCnt[Cfg::LCAP], bits[Cfg::LCAP];
@@ -122,7 +123,7 @@ MKT_HD uint32_t ws_bits16_ref(const uint8_t* win, uint32_t r0, uint32_t wlen) {
 template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t i, uint64_t& ws0, uint64_t& ws1) {
     const uint64_t* row = reinterpret_cast<const uint64_t*>(st.u.m.hmask[i]);
     const uint64_t A = row[0], B = row[1];
-    const uint32_t sh = st.off16[i] & 15u;
+    const uint32_t sh = st.goff[i] & 15u;
     ws0 = sh ? ((A >> sh) | (B << (64u - sh))) : A;
     ws1 = B >> sh;
 }
@@ -133,7 +134,7 @@ template <class Cfg> MKT_HD void fast_head_chunk_ref(FastState<Cfg>& st, const u
     for (uint32_t b = 0; b < 16u; ++b) {
         const uint64_t g = (uint64_t)G.w0 + r0 + b;
         const uint8_t ch = g < n ? text[g] : 0;
-        st.win[i * Cfg::HEADB + 16u * c + b] = ch;
+        st.win[i * Cfg::HSTRIDE + 16u * c + b] = ch;
         if (g < n && is_ws(ch)) m |= 1u << b;
     }
     st.u.m.hmask[i][c] = (uint16_t)m;
@@ -149,7 +150,7 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     uint64_t ws0, ws1;
     fast_head_ws(st, i, ws0, ws1);
     const uint32_t le = fast_line_end(st, G, i);                   // from the line table: no newline bitmap needed
-    const uint32_t room = (uint32_t)Cfg::HEADB - (off & 15u), reach = tv.n - gl;
+    const uint32_t room = (uint32_t)Cfg::HEADB - (st.goff[i] & 15u), reach = tv.n - gl;
     rec_clear(r, off);
     const int pf = parse_record_core(tv, off, P, r, ws0, ws1, le == kUnknown ? 0xFFFFu : le - gl, room < reach ? room : reach, reach);
     if (pf != PF_OK) {
@@ -170,7 +171,7 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
         const uint32_t poff = st.off16[i - 1];
         const uint32_t ql = r.qn_len;
         if (is_ws(tv.win[poff])) st.abn = AB_PREV_WS;
-        else if (ql + 1u > (uint32_t)Cfg::HEADB - (poff & 15u)) st.abn = AB_PREV_HEAD;          // beyond the previous line's head
+        else if (ql + 1u > (uint32_t)Cfg::HEADB - (st.goff[i - 1] & 15u)) st.abn = AB_PREV_HEAD;          // beyond the previous line's head
         else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql])) b |= LB_EQPREV;
     }
     st.bits[i] = b;

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                         const uint32_t b = __builtin_ctz(m);
                         const uint32_t r = ((v0 + k) << 4) + b + 1u;
                         st.goff[idx] = (uint16_t)r;
-                        st.off16[idx] = (uint16_t)(idx * (uint32_t)Cfg::HEADB + (r & 15u));
+                        st.off16[idx] = (uint16_t)(idx * (uint32_t)Cfg::HSTRIDE + (r & 15u));
                         ++idx;
                         m &= m - 1u;
                     }
@@ -497,7 +497,10 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                     }
                 }
             }
-            *reinterpret_cast<uint4*>(&st.win[i * (uint32_t)Cfg::HEADB + (c << 4)]) = q;
+            {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
+                uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE + (c << 4)]);
+                row[0] = q.x; row[1] = q.y; row[2] = q.z; row[3] = q.w;
+            }
             uint32_t m = pack16(ws_flags(q.x), ws_flags(q.y), ws_flags(q.z), ws_flags(q.w));
             if (g0 + 16u > n) m &= g0 < n ? (1u << (uint32_t)(n - g0)) - 1u : 0u;       // cleared bytes are not whitespace
             st.u.m.hmask[i][c] = (uint16_t)m;

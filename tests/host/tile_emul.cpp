@@ -29,7 +29,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     const TextView tv = fast_view(st, text, n, G);
     const uint8_t* win = text + G.w0;                          // the kernel streams these bytes through registers
     uint32_t NL = 0;
-    auto add_line = [&](uint32_t r) { st.goff[NL] = (uint16_t)r; st.off16[NL] = (uint16_t)(NL * FC::HEADB + (r & 15u)); ++NL; };
+    auto add_line = [&](uint32_t r) { st.goff[NL] = (uint16_t)r; st.off16[NL] = (uint16_t)(NL * FC::HSTRIDE + (r & 15u)); ++NL; };
     if (G.w0 == 0) add_line(0);
     for (uint32_t r = 0; r + 1 < wlen; ++r)
         if (win[r] == '\n') { if (NL == (uint32_t)FC::LCAP) return false; add_line(r + 1); }
