@@ -35,6 +35,7 @@ struct FastCfg {
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
     static constexpr int HSTRIDE = HEADB + 4;        // row pitch: 33 dwords, so lanes reading the same column of their own rows hit 32 different banks
     static constexpr int HW = LCAP_ * HSTRIDE;       // bytes of the head store
+    static constexpr int OWN = 28 * LCAP_;           // output dwords the emitter's owner table covers (more: binary search)
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
@@ -50,8 +51,12 @@ template <class Cfg>
 struct FastState {
     alignas(16) uint8_t win[Cfg::HW + 16];           // line heads, HEADB bytes per line, rows HSTRIDE apart
     // per line of the window
-    uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP];
-    uint32_t right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP];
+    union Recs {
+        struct { uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP], right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP]; } f;
+        // after the group phase the records are dead: the emitter keeps here, per aligned output dword of the tile's
+        // .pairs bytes, the ordinal of the reported pair whose line holds the dword's first byte
+        uint8_t own[Cfg::OWN];
+    } rc;
     uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HSTRIDE + (goff & 15)
     uint16_t goff[Cfg::LCAP];            // line start, window relative
     uint16_t flag[Cfg::LCAP];
@@ -158,8 +163,8 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
         else { st.bits[i] = 0; st.abn = AB_LONG; }                       // fields beyond the head: generic kernel
         return;
     }
-    st.pos[i] = r.pos; st.lclip[i] = (uint32_t)r.lclip; st.rclip[i] = (uint32_t)r.rclip; st.mappable[i] = (uint32_t)r.mappable;
-    st.right0[i] = (uint32_t)r.right0; st.left1[i] = (uint32_t)r.left1; st.right1[i] = (uint32_t)r.right1;
+    st.rc.f.pos[i] = r.pos; st.rc.f.lclip[i] = (uint32_t)r.lclip; st.rc.f.rclip[i] = (uint32_t)r.rclip; st.rc.f.mappable[i] = (uint32_t)r.mappable;
+    st.rc.f.right0[i] = (uint32_t)r.right0; st.rc.f.left1[i] = (uint32_t)r.left1; st.rc.f.right1[i] = (uint32_t)r.right1;
     st.flag[i] = (uint16_t)(r.flag & 0xFFFFu);
     st.qn_off[i] = (uint8_t)r.qn_off; st.qn_len[i] = (uint8_t)r.qn_len; st.rn_off[i] = (uint8_t)r.rn_off; st.rn_len[i] = (uint8_t)r.rn_len;
     st.segCnt[i] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
@@ -233,10 +238,10 @@ template <class Cfg> MKT_HD bool fast_is_start(FastState<Cfg>& st, const TextVie
 
 template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, uint32_t idx) {
     Seg s;
-    s.segCnt = st.segCnt[idx]; s.lclip = (int32_t)st.lclip[idx]; s.rclip = (int32_t)st.rclip[idx]; s.mappable = (int32_t)st.mappable[idx];
-    s.left0 = (int32_t)st.pos[idx]; s.left1 = (int32_t)st.left1[idx]; s.right0 = (int32_t)st.right0[idx]; s.right1 = (int32_t)st.right1[idx];
+    s.segCnt = st.segCnt[idx]; s.lclip = (int32_t)st.rc.f.lclip[idx]; s.rclip = (int32_t)st.rc.f.rclip[idx]; s.mappable = (int32_t)st.rc.f.mappable[idx];
+    s.left0 = (int32_t)st.rc.f.pos[idx]; s.left1 = (int32_t)st.rc.f.left1[idx]; s.right0 = (int32_t)st.rc.f.right0[idx]; s.right1 = (int32_t)st.rc.f.right1[idx];
     s.rightLast = s.segCnt == 2 ? s.right1 : s.right0;
-    s.flag = st.flag[idx]; s.pos = st.pos[idx];
+    s.flag = st.flag[idx]; s.pos = st.rc.f.pos[idx];
     s.chr_off = (uint32_t)st.off16[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];      // head-store offset
     return s;
 }
@@ -398,10 +403,22 @@ template <class Cfg> MKT_HD uint8_t fast_pair_byte(const FastState<Cfg>& st, uin
     const uint32_t i = g.em_idx[fast_pair_find(st, k)];
     return fast_layout_byte(st, g.g_slot[i], k - g.x_pair[i]);
 }
-// four consecutive output bytes k .. k+3 (little endian); bytes at or past `total` read as 0
-template <class Cfg> MKT_HD uint32_t fast_pair_bytes4(const FastState<Cfg>& st, uint32_t k, uint32_t total) {
+// owner table: the reported pair opened by line i owns every aligned output dword (head bytes h, then dword d at
+// byte h + 4 d) whose first byte lies in its line
+template <class Cfg> MKT_HD bool fast_own_fits(const FastState<Cfg>& st) { return st.sums.pair_bytes <= 4u * (uint32_t)Cfg::OWN; }
+template <class Cfg> MKT_HD void fast_own_fill(FastState<Cfg>& st, uint32_t i, uint32_t h) {
     const auto& g = st.u.g;
-    uint32_t ord = fast_pair_find(st, k);
+    if (!(g.g_info[i] & GI_EMIT)) return;
+    const uint32_t x = g.x_pair[i], e = x + g.g_plen[i];          // bytes [x, e) of the tile's output
+    if (e <= h) return;
+    const uint32_t dlo = x > h ? (x - h + 3u) >> 2 : 0u, dhi = (e - 1u - h) >> 2;
+    const uint8_t ord = g.x_emit[i];
+    for (uint32_t d = dlo; d <= dhi; ++d) st.rc.own[d] = ord;
+}
+// four consecutive output bytes k .. k+3 (little endian) starting in the line of reported pair `ord`; bytes at or past
+// `total` read as 0
+template <class Cfg> MKT_HD uint32_t fast_pair_bytes4(const FastState<Cfg>& st, uint32_t k, uint32_t total, uint32_t ord) {
+    const auto& g = st.u.g;
     uint32_t i = g.em_idx[ord], slot = g.g_slot[i], o = k - g.x_pair[i], plen = g.g_plen[i];
     uint32_t w = 0;
     for (uint32_t b = 0; b < 4u; ++b) {

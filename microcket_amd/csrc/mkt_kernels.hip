@@ -591,23 +591,25 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         STOP_AFTER(7)
 
         // ---- emit ----------------------------------------------------------------------------------
+        const uint32_t total = st.sums.pair_bytes;
+        uint8_t* const dst = s_out.pairs + st.base.pair_bytes;
+        const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);              // bytes before the first aligned dword
+        const uint32_t h = head < total ? head : total;
+        const bool own = fast_own_fits(st);
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
             fast_account(st, s_out, t, i);
             fast_last(st, G, &a.tile_last[t], i);
+            if (own) fast_own_fill(st, i, h);
         }
+        __syncthreads();
         {
-            const uint32_t total = st.sums.pair_bytes;
-            const uint64_t go = st.base.pair_bytes;
-            if (total && go + total <= s_out.pairs_cap) {
+            if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
                 // one lane per 4-byte-aligned output dword; the partial dwords at both ends go out as bytes
-                uint8_t* dst = s_out.pairs + go;
-                const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);      // bytes before the first aligned dword
-                const uint32_t h = head < total ? head : total;
                 if (tid < (int)h) dst[tid] = fast_pair_byte(st, (uint32_t)tid);
                 const uint32_t ndw = (total - h + 3u) >> 2;
                 for (uint32_t d = tid; d < ndw; d += NT) {
                     const uint32_t k = h + (d << 2);
-                    const uint32_t w = fast_pair_bytes4(st, k, total);
+                    const uint32_t w = fast_pair_bytes4(st, k, total, own ? (uint32_t)st.rc.own[d] : fast_pair_find(st, k));
                     if (k + 4u <= total) *reinterpret_cast<uint32_t*>(dst + k) = w;
                     else for (uint32_t b = 0; k + b < total; ++b) dst[k + b] = (uint8_t)(w >> (8u * b));
                 }

@@ -54,7 +54,7 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
         g.x_sam[i] = (uint32_t)s.sam_bytes;
         if (i < end_idx) {
             const uint32_t info = g.g_info[i];
-            g.x_grp[i] = (uint8_t)s.groups; g.x_sc[i] = (uint8_t)s.sc; g.x_pair[i] = (uint16_t)s.pair_bytes;
+            g.x_grp[i] = (uint8_t)s.groups; g.x_sc[i] = (uint8_t)s.sc; g.x_emit[i] = (uint8_t)s.emitted; g.x_pair[i] = (uint16_t)s.pair_bytes;
             if (info & GI_EMIT) g.em_idx[s.emitted] = (uint8_t)i;
             if (info & GI_START) ++s.groups;
             if (info & GI_EMIT) ++s.emitted;
@@ -71,8 +71,11 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     for (uint32_t i = first_idx; i < end_idx; ++i) { fast_account(st, out, t, i); fast_last(st, G, &tl, i); }
     // the kernel writes aligned dwords (fast_pair_bytes4) plus byte-wise ends: exercise both forms
     for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = fast_pair_byte(st, k);
-    for (uint32_t k = (t % 3); k < s.pair_bytes; k += 4) {
-        const uint32_t w = fast_pair_bytes4(st, k, s.pair_bytes);
+    const uint32_t hb = t % 4 < s.pair_bytes ? t % 4 : (uint32_t)s.pair_bytes;    // the kernel: alignment of the claimed output range
+    const bool own = fast_own_fits(st) && (t & 4) == 0;                         // ... owner table, or binary search when it does not fit
+    if (own) for (uint32_t i = first_idx; i < end_idx; ++i) fast_own_fill(st, i, hb);
+    for (uint32_t k = hb; k < s.pair_bytes; k += 4) {
+        const uint32_t w = fast_pair_bytes4(st, k, s.pair_bytes, own ? (uint32_t)st.rc.own[(k - hb) >> 2] : fast_pair_find(st, k));
         for (uint32_t b = 0; b < 4 && k + b < s.pair_bytes; ++b)
             if (out.pairs[run.pair_bytes + k + b] != (uint8_t)(w >> (8 * b))) { res.err |= 0x4000; }
     }
