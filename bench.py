@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--block-groups", type=int, default=1 << 21, help="read groups per block (one kernel pass); 2^21 groups = 1.9 GB of SAM text")
     ap.add_argument("--sam", default="no", choices=["no", "yes"])
     ap.add_argument("--read-len", type=int, default=150, help="read length of the synthetic data (BASELINE config: 150)")
-    ap.add_argument("--tiles", default="fast", choices=["fast", "auto"], help="tile geometry: the 32 KB lean tiles, or chosen per input")
+    ap.add_argument("--tiles", default="auto", choices=["fast", "auto"], help="tile geometry: chosen per input after a probe block (the library default), or the 48 KiB lean tiles forced")
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)

@@ -27,6 +27,8 @@ struct mkt_ctx {
     Params P;
     int cfg = CFG_FAST;
     int last_cfg = CFG_FAST;            // geometry of the newest resident block (mkt_fetch_last_block)
+    const uint8_t* last_text = nullptr; // its text (valid until the next sync: a failed probe block is re-run)
+    bool probing = true;                // the next resident block is looked at before more are queued
     hipStream_t stream = nullptr;
     size_t block_cap = 0;
     // device
@@ -194,10 +196,14 @@ void mkt_destroy(mkt_ctx* c) {
 
 static int ensure_sc_list(mkt_ctx* c, size_t need);
 
-// MKT_TILES_AUTO: when the 32 KB lean kernel leaves more than one tile in eight to the generic kernel (short lines
-// overflow its line table), the following blocks use the 16 KB geometry
-static void adapt_geometry(mkt_ctx* c, const BlockResult& r) {
-    if (c->p.tiles == MKT_TILES_AUTO && c->cfg == CFG_FAST && !c->p.ordered && r.tiles >= 8 && (uint64_t)r.pad * 8 > r.tiles) c->cfg = CFG_DENSE;
+// MKT_TILES_AUTO: when the lean kernel leaves more than one tile in eight to the generic kernel (short lines overflow
+// its line table), the following blocks use the next smaller geometry (48 -> 32 -> 16 KiB tiles)
+static bool adapt_geometry(mkt_ctx* c, const BlockResult& r) {
+    if (c->p.tiles == MKT_TILES_AUTO && !c->p.ordered && r.tiles >= 8 && (uint64_t)r.pad * 8 > r.tiles) {
+        if (c->cfg == CFG_FAST) { c->cfg = CFG_MID; return true; }
+        if (c->cfg == CFG_MID) { c->cfg = CFG_DENSE; return true; }
+    }
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -374,7 +380,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
         r = c->h_res[0];
         if (r.err == 0) break;
         if (attempt >= 3) return check_result(c, r);
-        if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg != CFG_SMALL && c->p.tiles == MKT_TILES_AUTO) { cfg = cfg == CFG_FAST ? CFG_DENSE : CFG_SMALL; continue; }
+        if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg != CFG_SMALL && c->p.tiles == MKT_TILES_AUTO) { cfg = cfg == CFG_FAST ? CFG_MID : (cfg == CFG_MID ? CFG_DENSE : CFG_SMALL); continue; }
         bool grew = false;
         const uint32_t nr = r.nregions ? r.nregions : 1;
         if (r.err & E_PAIRS_CAP) {
@@ -483,7 +489,7 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     // The self-circle list must have room for what the blocks in flight may add (their counts are known at the next sync)
     // ... and the first block of an input is a probe: its result (self-circle density, tiles the lean kernel could not
     // take) is looked at before the second block is queued
-    const bool probe = c->sc_density == 0 && c->res_used == 1;
+    const bool probe = c->probing && c->res_used >= 1;
     if (probe || c->res_used == c->res_slots || (size_t)c->acc.sc + sc_estimate(c, c->bytes_unsynced + n) > c->sc_cap) {
         if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "submit_device: sync before block (slots %zu/%zu, unsynced %.1f GB, density %.3g /B, list %llu of %zu)\n",
                                               c->res_used, c->res_slots, (double)c->bytes_unsynced / 1e9, c->sc_density, (unsigned long long)c->acc.sc, c->sc_cap);
@@ -497,7 +503,7 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     int rc = enqueue_block(c, (const uint8_t*)d_text, n, cfg_used, c->res_used);
     if (rc) return rc;
     ++c->res_used;
-    c->last_n = n; c->last_cfg = cfg_used;
+    c->last_n = n; c->last_cfg = cfg_used; c->last_text = (const uint8_t*)d_text;
     c->bytes_in += n;
     return MKT_OK;
 }
@@ -513,13 +519,26 @@ int mkt_sync(mkt_ctx* c) {
     fold_timing(c);
     const double t2 = dbg ? now() : 0;
     int rc = MKT_OK;
+    // A probe block (the only one in flight) whose line table overflowed is run again with the next smaller geometry:
+    // its text is still there and a failed block leaves the run totals alone.  Later blocks are not retried.
+    while (c->probing && c->res_used == 1 && c->res_folded == 0 && (c->h_res[0].err & (E_LINE_TABLE | E_OVF_SLOTS)) &&
+           c->p.tiles == MKT_TILES_AUTO && c->cfg != CFG_SMALL && c->last_text) {
+        c->cfg = c->cfg == CFG_FAST ? CFG_MID : (c->cfg == CFG_MID ? CFG_DENSE : CFG_SMALL);
+        c->last_cfg = c->cfg;
+        if ((rc = enqueue_block(c, c->last_text, c->last_n, c->cfg, 0))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        fold_timing(c);
+    }
+    bool changed = false;
     for (size_t k = c->res_folded; k < c->res_used; ++k) {
         const BlockResult& r = c->h_res[k];
-        if (r.err) { rc = check_result(c, r); break; }      // resident blocks are not retried: fail loudly
-        c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad; adapt_geometry(c, r);
+        if (r.err) { rc = check_result(c, r); break; }      // fail loudly
+        c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
+        changed = adapt_geometry(c, r) || changed;
         c->sc_unfolded += r.sc;
         ++c->blocks;
     }
+    if (c->res_used > c->res_folded) c->probing = changed;  // a new geometry is checked on one block before queueing ahead
     const size_t nres = c->res_used;
     c->res_used = 0; c->res_folded = 0;
     if (rc == MKT_OK) note_sc_density(c);
@@ -721,7 +740,7 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
     c->sc_unfolded = 0; c->bytes_unsynced = 0; c->keys_upper = 0;
-    c->sc_density = 0; c->cfg = c->p.tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;      // a new input is probed afresh
+    c->sc_density = 0; c->cfg = c->p.tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST; c->probing = true;      // a new input is probed afresh
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;

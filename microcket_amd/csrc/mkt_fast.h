@@ -20,10 +20,13 @@
 
 namespace mkt {
 
-// geometry of the production lean kernel (also what tests/host/tile_emul.cpp emulates as config 0 / 10)
-constexpr int kLeanTile = 32768, kLeanHB = 2048, kLeanHF = 3072, kLeanLCAP = 160;
-// ... and of its variant for short lines (reads of 50-75 bp: ~200-byte lines would overflow the 160-line table of a
-// 37 KB window); the host switches to it when the first blocks leave too many tiles to the generic kernel
+// Geometries of the production lean kernel (tests/host/tile_emul.cpp emulates them as configs 0/10, 5/15, 4/14).
+// Bigger tiles amortise the per-tile phases better and fill more lanes per phase, but the line table of a window is
+// bounded by LDS (~193 B per line): the 48 KiB tile fits lines of >= 330 B on average (150 bp reads), the 32 KiB one
+// >= 240 B (100 bp), the 16 KiB one >= 125 B (50 bp).  Under MKT_TILES_AUTO the host starts with the biggest and
+// steps down when a block leaves more than one tile in eight to the generic kernel.
+constexpr int kLeanTile = 49152, kLeanHB = 2048, kLeanHF = 3072, kLeanLCAP = 168;
+constexpr int kMidTile = 32768, kMidHB = 2048, kMidHF = 3072, kMidLCAP = 160;
 constexpr int kDenseTile = 16384, kDenseHB = 1024, kDenseHF = 2048, kDenseLCAP = 160;
 
 template <int TILE_, int HB_, int HF_, int LCAP_>

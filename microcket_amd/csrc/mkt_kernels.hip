@@ -779,23 +779,29 @@ hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_grou
 }
 
 // ---------------------------------------------------------------------------------------------
-typedef TileCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, 256, 4> CfgFast;      // same tile index space as the lean kernel
-typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;             // ... and as its short-line variant
+typedef TileCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, 512, 4> CfgFast;      // same tile index space as the lean kernel
+typedef TileCfg<kMidTile, kMidHB, kMidHF, 512, 4> CfgMid;                    // ... and as its variants for shorter lines
+typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
+typedef FastCfg<kMidTile, kMidHB, kMidHF, kMidLCAP> CfgLeanMid;
 typedef FastCfg<kDenseTile, kDenseHB, kDenseHF, kDenseLCAP> CfgLeanDense;
 
-uint32_t tile_bytes(int cfg) { return cfg == CFG_SMALL ? CfgSmall::TILE : (cfg == CFG_DENSE ? CfgDense::TILE : CfgFast::TILE); }
+uint32_t tile_bytes(int cfg) {
+    return cfg == CFG_SMALL ? CfgSmall::TILE : (cfg == CFG_DENSE ? CfgDense::TILE : (cfg == CFG_MID ? CfgMid::TILE : CfgFast::TILE));
+}
 
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
     if (cfg == CFG_SMALL) hipLaunchKernelGGL(k_tiles<CfgSmall>, dim3(grid), dim3(NT), 0, s, a);
     else if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_tiles<CfgDense>, dim3(grid), dim3(NT), 0, s, a);
+    else if (cfg == CFG_MID) hipLaunchKernelGGL(k_tiles<CfgMid>, dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(k_tiles<CfgFast>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
     if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_fast<CfgLeanDense>, dim3(grid), dim3(NT), 0, s, a);
+    else if (cfg == CFG_MID) hipLaunchKernelGGL(k_fast<CfgLeanMid>, dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(k_fast<CfgLean>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }

@@ -7,7 +7,7 @@
 
 namespace mkt {
 
-enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2 };      // tile geometries: 32 KB lean, 256 B generic only, 16 KB lean (short lines)
+enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2, CFG_MID = 3 };      // tile geometries: 48 KiB lean, 256 B generic only, 16 KiB lean, 32 KiB lean
 
 // totals of the blocks a context has finished, kept on the device so that resident blocks chain
 // without a host round trip

@@ -174,11 +174,12 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
     pairs.resize(run.pair_bytes); sam.resize(run.sam_bytes); sc.resize(sc_base + run.sc);
 }
 
-typedef TileCfg<kLeanTile, kLeanHB, kLeanHF, 256, 4> CfgFast;          // the production geometry
+typedef TileCfg<kLeanTile, kLeanHB, kLeanHF, 512, 4> CfgFast;          // the production geometry
 typedef TileCfg<256, 64, 192, 512, 4> CfgSafe;
 typedef TileCfg<1024, 128, 512, 96, 4> CfgMid;
 typedef TileCfg<2048, 16, 16, 128, 4> CfgNoHalo;
-typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;          // the production short-line geometry
+typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;          // the production short-line geometries
+typedef TileCfg<kMidTile, kMidHB, kMidHF, 512, 4> CfgMid32;
 
 // One emulated shard / input stream (mirrors a mkt_ctx of the library: feed, group count, finish).
 struct EmulShard {
@@ -214,6 +215,7 @@ static void emul_feed(EmulShard& S, const char* text, size_t n, size_t block_byt
         case 2: emul_block<CfgMid>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         case 3: emul_block<CfgNoHalo>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         case 4: emul_block<CfgDense, kDenseLCAP>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
+        case 5: emul_block<CfgMid32, kMidLCAP>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         default: emul_block<CfgFast, kLeanLCAP>(b, (uint32_t)take, S.P, bp, bs, S.sc, S.acc.groups, r, lean); break;
         }
         S.lean_tiles += r.pad; S.tiles += r.tiles;

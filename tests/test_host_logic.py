@@ -11,8 +11,8 @@ import pytest
 
 import util
 
-CFGS = {0: "production 32K tile", 1: "small 256 B tile", 2: "mid 1K tile", 3: "2K tile, 16 B halos", 4: "production 16K tile (short lines)",
-        10: "lean path + generic for deferred tiles, 32K tile", 12: "lean + generic, 1K tile", 13: "lean + generic, 2K tile / 16 B halos",
+CFGS = {0: "production 48K tile", 5: "production 32K tile", 15: "lean + generic, 32K tile", 1: "small 256 B tile", 2: "mid 1K tile", 3: "2K tile, 16 B halos", 4: "production 16K tile (short lines)",
+        10: "lean path + generic for deferred tiles, 48K tile", 12: "lean + generic, 1K tile", 13: "lean + generic, 2K tile / 16 B halos",
         14: "lean + generic, 16K tile"}
 
 
@@ -27,7 +27,7 @@ def _check(text, mode, T, ratio, mapq, sam, cfg, block):
     assert es["groups"] == st.groups, tag
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 10, 12, 13, 14])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 10, 12, 13, 14, 15])
 @pytest.mark.parametrize("name", ["edge_unc.sam", "edge_flash.sam"])
 def test_tile_phases_edge_fixtures(name, cfg):
     text = open(os.path.join(util.GOLDEN, name), "rb").read()
@@ -37,7 +37,7 @@ def test_tile_phases_edge_fixtures(name, cfg):
                 _check(text, mode, T, ratio, mapq, sam, cfg, block)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 10, 12, 13, 14])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 10, 12, 13, 14, 15])
 @pytest.mark.parametrize("profile,seed,groups,modes", [
     ("unc", 11, 1500, ("unc",)), ("flash", 12, 1500, ("flash",)), ("stress", 13, 4000, ("unc", "flash")),
 ])
@@ -69,5 +69,5 @@ def test_long_fields_take_the_generic_parser():
     q = b"Q" * 300
     text = (q + b"\t65\tchr1\t1000\t60\t150M\t=\t1\t0\tA\tF\n" + q + b"\t129\tchrUn_" + b"x" * 200 + b"\t9000\t60\t150M\t=\t1\t0\tA\tF\n"
             + b"z\t65\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF\nz\t129\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF\n")
-    for cfg in (0, 1, 2, 3, 4, 10, 12, 13, 14):
+    for cfg in (0, 1, 2, 3, 4, 5, 10, 12, 13, 14, 15):
         _check(text, "unc", 4, 0.5, 10, True, cfg, 0)
