@@ -55,6 +55,29 @@ struct ScanScratch { uint64_t a[NT / 64], b[NT / 64]; };
 __device__ inline uint64_t shfl_up64(uint64_t v, int d) { return (uint64_t)__shfl_up((long long)v, d, 64); }
 __device__ inline uint64_t shfl_xor64(uint64_t v, int d) { return (uint64_t)__shfl_xor((long long)v, d, 64); }
 
+// exclusive scan of one u32 per thread over the workgroup; the total returned to every thread
+__device__ inline void block_exscan1(uint32_t& a, uint32_t& total, ScanScratch& sc) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t ia = a;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)ia, d, 64);
+        if (lane >= d) ia += x;
+    }
+    if (lane == 63) sc.a[wv] = ia;
+    __syncthreads();
+    uint32_t pre = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint32_t x = (uint32_t)sc.a[w];
+        if (w < wv) pre += x;
+        total += x;
+    }
+    a = pre + ia - a;
+    __syncthreads();
+}
+
 // exclusive scan of two u64 lanes-values over the workgroup; totals returned to every thread
 __device__ inline void block_exscan2(uint64_t& a, uint64_t& b, uint64_t& ta, uint64_t& tb, ScanScratch& sc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -95,6 +118,11 @@ __device__ inline uint32_t ws_bits(uint32_t x) {
 __device__ inline uint32_t nl_flags(uint32_t x) {                 // byte == '\n'
     const uint32_t y = x & 0x7F7F7F7Fu;
     return ~((y ^ 0x0A0A0A0Au) + 0x7F7F7F7Fu) & ~x & 0x80808080u;
+}
+// nonzero iff some byte of x is '\n' (exact as a yes/no; which byte is not)
+__device__ inline uint32_t has_nl(uint32_t x) {
+    const uint32_t t = x ^ 0x0A0A0A0Au;
+    return (t - 0x01010101u) & ~t & 0x80808080u;
 }
 __device__ inline uint32_t ws_flags(uint32_t x) {                 // byte in {9..13, 32}
     const uint32_t y = x & 0x7F7F7F7Fu;
@@ -420,11 +448,24 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                     // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
                     if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
+                // ... then the math.  One vector in ~21 holds a newline: an exact 4-op-per-dword "any byte == '\\n'" test
+                // sorts them out, and only those go through the flag packing (each lane loops over its own hits)
+                uint32_t hit = 0;
 #pragma unroll
-                for (int k = 0; k < BATCH; ++k) {              // ... then the math
+                for (int k = 0; k < BATCH; ++k) {
                     const uint32_t v = tid + (k0 + k) * NT;
                     if (k0 + k >= LPT || v >= nvec) continue;
-                    uint32_t mnl = pack16(nl_flags(x[k].x), nl_flags(x[k].y), nl_flags(x[k].z), nl_flags(x[k].w));
+                    if (has_nl(x[k].x) | has_nl(x[k].y) | has_nl(x[k].z) | has_nl(x[k].w)) hit |= 1u << k;
+                    else nlmask[v] = 0;
+                }
+                while (hit) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(hit);
+                    hit &= hit - 1u;
+                    uint4 y = x[0];
+#pragma unroll
+                    for (int j = 1; j < BATCH; ++j) if (k == (uint32_t)j) y = x[j];
+                    const uint32_t v = tid + ((uint32_t)k0 + k) * NT;
+                    uint32_t mnl = pack16(nl_flags(y.x), nl_flags(y.y), nl_flags(y.z), nl_flags(y.w));
                     const uint32_t r0 = v << 4;
                     if (r0 + 16u > wlen) mnl &= (1u << (wlen - r0)) - 1u;      // bytes past the end of the window / block
                     nlmask[v] = (uint16_t)mnl;
@@ -443,27 +484,38 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 if (r0 + 16u > wlen - 1u) { const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u; m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u); }
                 return m;
             };
-            uint64_t cnt = 0, dummy = 0, total, td;
+            // this lane's VPT consecutive vectors as 64-bit words of newline bits (4 vectors per word), kept in registers
+            constexpr int NW = (VPT + 3) / 4;
             const uint32_t v0 = tid * VPT;
-            for (uint32_t k = 0; k < (uint32_t)VPT; ++k) if (v0 + k < nvec) cnt += __popc(line_bits(v0 + k));
-            uint64_t ex = cnt;
-            block_exscan2(ex, dummy, total, td, scan);
+            uint64_t mw[NW];
+            uint32_t cnt = 0, total;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) mw[w] = 0;
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) {
+                const uint32_t m = v0 + (uint32_t)k < nvec ? line_bits(v0 + (uint32_t)k) : 0u;
+                mw[k >> 2] |= (uint64_t)m << (16 * (k & 3));
+            }
+#pragma unroll
+            for (int w = 0; w < NW; ++w) cnt += (uint32_t)__popcll(mw[w]);
+            uint32_t ex = cnt;
+            block_exscan1(ex, total, scan);
             const uint32_t lead = G.w0 == 0 ? 1u : 0u;
-            const uint32_t NLt = (uint32_t)total + lead;
+            const uint32_t NLt = total + lead;
             if (NLt > (uint32_t)Cfg::LCAP) {
                 if (tid == 0) { st.abn = AB_LCAP; st.NL = 0; }
             } else {
-                uint32_t idx = (uint32_t)ex + lead;
-                for (uint32_t k = 0; k < (uint32_t)VPT; ++k) {
-                    if (v0 + k >= nvec) break;
-                    uint32_t m = line_bits(v0 + k);
+                uint32_t idx = ex + lead;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    uint64_t m = mw[w];
                     while (m) {
-                        const uint32_t b = __builtin_ctz(m);
-                        const uint32_t r = ((v0 + k) << 4) + b + 1u;
+                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
+                        const uint32_t r = ((v0 + 4u * (uint32_t)w) << 4) + b + 1u;
                         st.goff[idx] = (uint16_t)r;
                         st.off16[idx] = (uint16_t)(idx * (uint32_t)Cfg::HSTRIDE + (r & 15u));
                         ++idx;
-                        m &= m - 1u;
+                        m &= m - 1ull;
                     }
                 }
                 if (tid == 0) {
