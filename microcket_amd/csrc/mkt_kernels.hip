@@ -422,6 +422,8 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     unsigned long long stamp_prev_ = 0;
 #endif
 
+    __shared__ uint32_t wg_cnt[C_COUNT];                  // this workgroup's share of the block's counters
+    if (tid0 < (int)C_COUNT) wg_cnt[tid0] = 0;
     // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         int tid = tid0;
@@ -455,8 +457,12 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 for (int k = 0; k < BATCH; ++k) {
                     const uint32_t v = tid + (k0 + k) * NT;
                     if (k0 + k >= LPT || v >= nvec) continue;
+#if defined(MKT_DIAG_SCAN_NOMATH)
+                    nlmask[v] = (uint16_t)(x[k].x ^ x[k].y ^ x[k].z ^ x[k].w);
+#else
                     if (has_nl(x[k].x) | has_nl(x[k].y) | has_nl(x[k].z) | has_nl(x[k].w)) hit |= 1u << k;
                     else nlmask[v] = 0;
+#endif
                 }
                 while (hit) {
                     const uint32_t k = (uint32_t)__builtin_ctz(hit);
@@ -695,10 +701,11 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         }
         __syncthreads();
         STAMP(8);
-        if (tid < (int)C_COUNT && st.cnt[tid]) atomicAdd(&a.res->counters[tid], st.cnt[tid]);
-        if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
+        if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];        // flushed once per workgroup: 9 global atomics per TILE on one
+        if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);      // cache line would queue up behind each other
         __syncthreads();
     }
+    if (tid0 < (int)C_COUNT && wg_cnt[tid0]) atomicAdd(&a.res->counters[tid0], wg_cnt[tid0]);
 }
 
 // After the tiles, step 1 (one workgroup per 1024 tiles): exclusive scan of the per-tile group counts
