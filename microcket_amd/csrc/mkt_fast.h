@@ -10,10 +10,10 @@
 // LDS holds only what the parser reads: the HEAD of every line (the HEADB = 128 bytes of the eight
 // aligned 16-byte chunks that start at the chunk holding the line's first byte).  SEQ / QUAL / tags,
 // 60 % of the bytes, stream through registers once for the newline scan and never touch LDS, so a
-// 32 KB tile (+ halos) costs 20 KB of LDS instead of 38 KB and twice as many lines are in flight per
-// CU.  `off16` are offsets into that compact head store (what all text code uses); `goff` are the
-// true window-relative line starts (geometry, line lengths).  State is packed (16-bit offsets,
-// 8-bit field lengths): one tile is about 36 KB of LDS, four workgroups per CU.  The phase functions
+// 48 KB tile (+ halos) costs 22 KB of head store instead of a 53 KB window and three times as many
+// lines are in flight per CU.  `off16` are offsets into that compact head store (what all text code
+// uses); `goff` are the true window-relative line starts (geometry, line lengths).  State is packed
+// (16-bit offsets, 8-bit field lengths): one tile is 39 KB of LDS, four workgroups per CU.  The phase functions
 // are host+device so that tests/host/tile_emul.cpp checks this logic on the CPU as well.
 #pragma once
 #include "mkt_tile.h"
