@@ -15,7 +15,7 @@
 
 // tile geometry of the fast configuration (the lean and the generic kernel must agree on TILE)
 #ifndef MKT_RR
-#define MKT_RR 4          // waves that share the group phase of a tile (lines dealt round-robin)
+#define MKT_RR 2          // waves that share the group phase of a tile (lines dealt round-robin; 2 beats 1, 3 and 4 at 48 KiB tiles)
 #endif
 #ifndef MKT_LEAN_TILE      // experiments override the geometry of mkt_fast.h
 #define MKT_LEAN_TILE kLeanTile
@@ -457,12 +457,8 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 for (int k = 0; k < BATCH; ++k) {
                     const uint32_t v = tid + (k0 + k) * NT;
                     if (k0 + k >= LPT || v >= nvec) continue;
-#if defined(MKT_DIAG_SCAN_NOMATH)
-                    nlmask[v] = (uint16_t)(x[k].x ^ x[k].y ^ x[k].z ^ x[k].w);
-#else
                     if (has_nl(x[k].x) | has_nl(x[k].y) | has_nl(x[k].z) | has_nl(x[k].w)) hit |= 1u << k;
                     else nlmask[v] = 0;
-#endif
                 }
                 while (hit) {
                     const uint32_t k = (uint32_t)__builtin_ctz(hit);
