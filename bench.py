@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- read-pairs/s through the sam2pairs hot path on MI355X (BASELINE.json's metric).
+"""bench.py -- read-pairs/s through sam2pairs+dedup on MI355X (BASELINE.json's metric).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -8,7 +8,10 @@
 Workload (config.workload): BASELINE.json configs[1] -- 100 M synthetic 150 bp PE read pairs with
 hg38 chromosome names (seeded generator), unstitched mode, sam=no (the driver's -x),
 ~92 GB of SAM text resident in HBM per GPU before the timed region starts.  One STEP = one pass
-of the hot path over the whole resident data set (all blocks).  N > 1: every rank holds its own
+of the hot path over the whole resident data set (all blocks) followed by the duplicate marking of the
+reported pairs and the per-chromosome-pair counts (BASELINE.json: "sam2pairs+dedup"; both are extensions
+that the reference's sam2pairs does not have, so the same steps WITHOUT them -- exactly the reference's
+behaviour and outputs -- are timed too and reported as `sam2pairs_only`; `--dedup no` makes that the value).  N > 1: every rank holds its own
 100 M-pair shard (weak scaling; shard r = groups [r*P, (r+1)*P) of one seeded data set); the only
 exchange is the group-count all_gather + 8-counter all_reduce at the end (quirks Q1/Q2).
 
@@ -56,16 +59,24 @@ def cpu_baseline(ctx, ds, sample_groups, threads):
                 nbytes += n
                 if groups >= sample_groups:
                     break
-        t0 = time.time()
-        with open(os.devnull, "wb") as null:
-            rc = subprocess.run([exe, path, "unc", os.path.join(d, "out"), str(threads), "0.5", "10", "no"], stdout=null,
-                                stderr=subprocess.PIPE).returncode
-        dt = time.time() - t0
+        def run_ref(nthreads):
+            t0 = time.time()
+            with open(os.devnull, "wb") as null:
+                rc = subprocess.run([exe, path, "unc", os.path.join(d, "out"), str(nthreads), "0.5", "10", "no"], stdout=null,
+                                    stderr=subprocess.PIPE).returncode
+            return rc, time.time() - t0
+        rc, dt = run_ref(threads)
         if rc != 0:
             return None
-        return {"value": groups / dt, "unit": "read-pairs/s", "cores": threads if kind == "reference" else 1, "kind": kind,
-                "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input, sam=no, thread={threads}, {dt:.1f} s",
-                "host_cpus": os.cpu_count()}
+        out = {"value": groups / dt, "unit": "read-pairs/s", "cores": threads if kind == "reference" else 1, "kind": kind,
+               "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input, sam=no, thread={threads}, {dt:.1f} s",
+               "host_cpus": os.cpu_count()}
+        many = min(os.cpu_count() or 1, 64)
+        if kind == "reference" and many > threads:              # also at thread = min(nproc, 64)
+            rc2, dt2 = run_ref(many)
+            if rc2 == 0:
+                out["more_threads"] = {"cores": many, "value": groups / dt2, "seconds": dt2}
+        return out
     finally:
         try:
             for fn in os.listdir(d):
@@ -86,6 +97,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=150, help="read length of the synthetic data (BASELINE config: 150)")
     ap.add_argument("--tiles", default="auto", choices=["fast", "auto"], help="tile geometry: chosen per input after a probe block (the library default), or the 48 KiB lean tiles forced")
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
+    ap.add_argument("--dedup", default="yes", choices=["yes", "no"],
+                    help="yes (BASELINE.json's metric, sam2pairs+dedup): every step also marks duplicate pairs and counts chromosome pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
@@ -124,47 +137,69 @@ def main():
 
     tdev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
 
-    def dev_sync():
-        if torch is not None and tdev == "cuda" and torch.cuda.is_available():
-            torch.cuda.synchronize()
-        ctx.sync()
-
     profile = 0 if args.mode == "unc" else 1
     seed = 20260104 + 1  # seeds 20260104 + config index
-    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=m.TILES_FAST if args.tiles == "fast" else m.TILES_AUTO)
+    tiles = m.TILES_FAST if args.tiles == "fast" else m.TILES_AUTO
+    dedup = args.dedup == "yes"
+    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=tiles, extensions=m.EXT_KEYS if dedup else 0)
     t0 = time.time()
     ds = ctx.dataset(seed, profile, args.pairs, args.block_groups, first_group=rank * args.pairs, genome=0, read_len=args.read_len, lanes=1,
                      tail_group=(rank == world - 1))
     log(f"[rank {rank}] data set: {ds.total_groups} pairs, {ds.total_bytes / 1e9:.2f} GB in {ds.n_blocks} blocks, generated in {time.time() - t0:.1f} s")
+    drop_last = rank == world - 1          # every rank holds pairs; the input's end is on the last one (quirk Q1)
+    ext_out = {}
 
-    def one_pass():
-        for (p, n, _g) in ds.blocks:
-            ctx.submit_device(p, n)
+    def run_steps(c, steps, with_dedup):
+        """`steps` passes of the hot path over the resident data set.  With dedup every step is a whole input: sam2pairs over all
+        blocks, then duplicate marking of the reported pairs and the per-chromosome-pair counts (this rank's shard)."""
+        for _ in range(steps):
+            if with_dedup:
+                c.reset()
+            for (p, n, _g) in ds.blocks:
+                c.submit_device(p, n)
+            if with_dedup:
+                tot, dups, _ = c.ext_dedup(drop_last, want_flags=False)
+                rows = c.ext_chrstat(drop_last)
+                ext_out.update(reported_pairs=tot, duplicates=dups, chrstat_rows=len(rows.splitlines()))
+        c.sync()
 
-    for _ in range(max(args.warmup, 0)):
-        one_pass()
-    ctx.sync()
-    ctx.reset()
-    ctx.reset_timing()
+    def timed(c, with_dedup):
+        run_steps(c, max(args.warmup, 0), with_dedup)
+        if not with_dedup:
+            c.reset()
+        c.reset_timing()
+        # ---- timed region: exactly K steps
+        if torch is not None and tdev == "cuda" and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        c.sync(); barrier()
+        t_start = time.perf_counter()
+        run_steps(c, args.steps, with_dedup)
+        if torch is not None and tdev == "cuda" and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        c.sync(); barrier()
+        el = time.perf_counter() - t_start
+        if dist is not None:
+            tt = torch.tensor([el], dtype=torch.float64, device=tdev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, c.timing()
 
-    # ---- timed region: exactly K steps (each one pass over the resident data set)
-    dev_sync(); barrier()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-    ctx.sync()
-    dev_sync(); barrier()
-    elapsed = time.perf_counter() - t_start
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    tmg = ctx.timing()
+    elapsed, tmg = timed(ctx, dedup)
     tm_ms, tm_launch, tm_bytes = tmg.tile_kernel_ms, tmg.tile_launches, tmg.tile_bytes
+    tiles_seen, tiles_deferred = tmg.tiles, tmg.deferred_tiles
+
+    # the same passes without the extensions (exactly the reference's behaviour and outputs), on a second context
+    plain = None
+    if dedup:
+        ctx2 = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=tiles)
+        el2, tmg2 = timed(ctx2, False)
+        plain = (el2, tmg2.tile_kernel_ms, tmg2.tile_launches)
+        ctx2.close()
 
     # ---- one more (untimed) pass for the end-of-input bookkeeping and the counters of ONE pass
     ctx.reset()
-    one_pass()
+    for (p, n, _g) in ds.blocks:
+        ctx.submit_device(p, n)
     my_groups = ctx.group_count()
     if dist is not None:
         gl = [None] * world
@@ -173,13 +208,14 @@ def main():
         total = sum(gl)
         last_nonempty = max(i for i, g in enumerate(gl) if g > 0)
         st = ctx.finish(drop_last=(rank == last_nonempty), group_offset=offset, total_groups=total)
-        cnt = torch.tensor([st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes],
-                           dtype=torch.int64, device=tdev)
+        cnt = torch.tensor([st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes,
+                            ext_out.get("duplicates", 0)], dtype=torch.int64, device=tdev)
         dist.all_reduce(cnt)
         counters = [int(x) for x in cnt.tolist()]
     else:
         st = ctx.finish(True)
-        counters = [st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes]
+        counters = [st.lowMap, st.manyHits, st.unpaired, st.selfCircle, st.trans, st.cis10K, st.cis1K, st.cis0, st.pairs, st.pair_bytes,
+                    ext_out.get("duplicates", 0)]
 
     pairs_per_step = ds.total_groups
     out_bytes_step = st.pair_bytes + (st.sam_bytes if args.sam == "yes" else 0)
@@ -199,7 +235,7 @@ def main():
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
             if cands and tm_launch and args.read_len == 150 and args.sam == "no" and args.mode == "unc":
                 tj = json.loads(open(cands[-1]).read())
-                if tj.get("block_groups") == args.block_groups:
+                if tj.get("block_groups") == args.block_groups and ("duplicate marking" in tj.get("workload", "")) == dedup:
                     traffic = tj["traffic_over_algorithmic"] * algo_bytes_step * args.steps / tm_launch
                     traffic_src = f"profiles/{os.path.basename(cands[-1])}: traffic/algorithmic = {tj['traffic_over_algorithmic']:.3f} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
@@ -208,7 +244,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(ctx, ds, args.cpu_sample_pairs, 8)
         result = {
-            "metric": "read-pairs/sec through sam2pairs (150 bp PE, hg38 names, SAM text resident in HBM)",
+            "metric": ("read-pairs/sec through sam2pairs+dedup" if dedup else "read-pairs/sec through sam2pairs") + " (150 bp PE, hg38 names, SAM text resident in HBM)",
             "value": value,
             "unit": "read-pairs/s",
             "n_gpus": world,
@@ -222,7 +258,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"C2: {args.pairs} synthetic {args.read_len} bp PE read pairs per GPU, hg38 chromosome names, {args.mode} mode, sam={args.sam}, "
-                            f"seed {seed}, one step = one pass over the whole resident data set",
+                            f"seed {seed}, one step = one pass over the whole resident data set"
+                            + (" + duplicate marking of the reported pairs on (chr1,pos1,chr2,pos2,strands) + per-chromosome-pair counts" if dedup else ""),
                 "pairs_per_gpu": ds.total_groups,
                 "sam_bytes_per_gpu": ds.total_bytes,
                 "bytes_per_pair_in": ds.total_bytes / ds.total_groups,
@@ -244,12 +281,20 @@ def main():
                 "launches": tm_launch,
                 "avg_launch_ms": tm_ms / tm_launch if tm_launch else None,
                 "algorithmic_bytes_per_launch": algo_bytes_step * args.steps / tm_launch if tm_launch else None,
-                "tiles": tmg.tiles,
-                "tiles_left_to_generic_kernel": tmg.deferred_tiles,
+                "tiles": tiles_seen,
+                "tiles_left_to_generic_kernel": tiles_deferred,
             },
             "cpu_baseline": cpu,
-            "counters": dict(zip(["lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0", "pairs", "pair_bytes"], counters)),
+            "counters": dict(zip(["lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0", "pairs", "pair_bytes", "duplicates"], counters)),
         }
+        if dedup:
+            result["dedup"] = dict(ext_out, scope="per GPU shard (cross-shard reconciliation: microcket_amd.shard.dedup_sharded, not part of the step)",
+                                   note="extension, not in the reference's sam2pairs: default off in the library, never changes stdout/.sam/.log")
+            el2, ms2, ln2 = plain
+            ach2 = (algo_bytes_step * args.steps) / (ms2 / 1e3) / 1e9 if ms2 > 0 else 0.0
+            result["sam2pairs_only"] = {"value": total_pairs / el2, "unit": "read-pairs/s", "ms_per_step": el2 / args.steps * 1e3,
+                                        "note": "the same steps without the extensions: exactly the reference's behaviour and outputs",
+                                        "roofline": {"achieved": ach2, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS, "avg_launch_ms": ms2 / ln2 if ln2 else None}}
         if cpu:
             result["speedup_vs_cpu_baseline"] = value / cpu["value"]
     ds.close()

@@ -251,9 +251,13 @@ class Context:
 
     def ext_chrstat(self, drop_last=True):
         n = C.c_size_t()
-        self._chk(self.L.mkt_ext_chrstat(self.h, 1 if drop_last else 0, None, 0, C.byref(n)), "mkt_ext_chrstat")
-        buf = C.create_string_buffer(max(n.value, 1))
-        self._chk(self.L.mkt_ext_chrstat(self.h, 1 if drop_last else 0, buf, n.value, C.byref(n)), "mkt_ext_chrstat")
+        cap = 1 << 20                          # one call in the usual case (the table is a few KB)
+        buf = C.create_string_buffer(cap)
+        rc = self.L.mkt_ext_chrstat(self.h, 1 if drop_last else 0, buf, cap, C.byref(n))
+        if rc != 0 and n.value > cap:          # too small: *len holds the size needed
+            buf = C.create_string_buffer(n.value)
+            rc = self.L.mkt_ext_chrstat(self.h, 1 if drop_last else 0, buf, n.value, C.byref(n))
+        self._chk(rc, "mkt_ext_chrstat")
         return buf.raw[:n.value]
 
     def group_count(self):

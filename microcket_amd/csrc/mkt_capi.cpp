@@ -37,6 +37,10 @@ struct mkt_ctx {
     uint8_t* d_sam = nullptr; size_t sam_cap = 0;
     uint64_t* d_sc = nullptr; size_t sc_cap = 0;          // the run's resolved self-circle list (drained at syncs)
     unsigned long long* d_sc_logged = nullptr;            // result word of k_sc_logged
+    uint8_t* h_chr_stage = nullptr; uint16_t* d_dense = nullptr;              // mkt_ext_chrstat: pinned staging, slot -> dense id
+    uint8_t* d_dd_flags = nullptr; size_t dd_flags_cap = 0; void* d_dd_work = nullptr; size_t dd_work_cap = 0;      // mkt_ext_dedup
+    DedupResult* d_dd_res = nullptr; DedupResult* h_dd_res = nullptr;
+    unsigned long long* d_chr_counts = nullptr; unsigned long long* h_chr_counts = nullptr; size_t chr_counts_cap = 0;
     double sc_density = 0;                                // most self-circles per input byte seen between two syncs (0: nothing seen yet)
     uint64_t* d_sc_tmp = nullptr; size_t sc_tmp_cap = 0;  // per block: raw (tile, ordinal) entries, one slice per region
     // extensions (MKT_EXT_KEYS)
@@ -190,6 +194,14 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->d_sc_logged) (void)hipFree(c->d_sc_logged);
+    if (c->h_chr_stage) (void)hipHostFree(c->h_chr_stage);
+    if (c->d_dd_flags) (void)hipFree(c->d_dd_flags);
+    if (c->d_dd_work) (void)hipFree(c->d_dd_work);
+    if (c->d_dd_res) (void)hipFree(c->d_dd_res);
+    if (c->h_dd_res) (void)hipHostFree(c->h_dd_res);
+    if (c->d_dense) (void)hipFree(c->d_dense);
+    if (c->d_chr_counts) (void)hipFree(c->d_chr_counts);
+    if (c->h_chr_counts) (void)hipHostFree(c->h_chr_counts);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -621,18 +633,29 @@ int mkt_ext_dedup(mkt_ctx* c, int drop_last, uint64_t* total, uint64_t* dups, ui
     if (dups) *dups = 0;
     if (n == 0) return MKT_OK;
     if (flags && flags_cap < n) return fail(c, MKT_E_ARG, "flags buffer too small (%llu needed)", (unsigned long long)n);
-    uint8_t* d_flags = nullptr; void* d_work = nullptr; DedupResult* d_res = nullptr;
+    // work buffers are kept between calls (GB-sized hipMalloc / hipFree pairs cost more than the marking itself)
     const size_t wb = dedup_work_bytes(n);
-    HIPCHK(c, hipMalloc((void**)&d_flags, n));
-    HIPCHK(c, hipMalloc(&d_work, wb));
-    HIPCHK(c, hipMalloc((void**)&d_res, sizeof(DedupResult)));
-    HIPCHK(c, launch_dedup(c->d_key_list, n, d_flags, d_work, wb, d_res, c->stream));
-    DedupResult r;
-    HIPCHK(c, hipMemcpyAsync(&r, d_res, sizeof r, hipMemcpyDeviceToHost, c->stream));
-    if (flags) HIPCHK(c, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, c->stream));
+    if (c->dd_flags_cap < n) {
+        if (c->d_dd_flags) HIPCHK(c, hipFree(c->d_dd_flags));
+        c->d_dd_flags = nullptr; c->dd_flags_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_dd_flags, n + n / 8 + 4096));
+        c->dd_flags_cap = n + n / 8 + 4096;
+    }
+    if (c->dd_work_cap < wb) {
+        if (c->d_dd_work) HIPCHK(c, hipFree(c->d_dd_work));
+        c->d_dd_work = nullptr; c->dd_work_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_dd_work, wb + wb / 8));
+        c->dd_work_cap = wb + wb / 8;
+    }
+    if (!c->d_dd_res) {
+        HIPCHK(c, hipMalloc((void**)&c->d_dd_res, sizeof(DedupResult)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_dd_res, sizeof(DedupResult), hipHostMallocDefault));
+    }
+    HIPCHK(c, launch_dedup(c->d_key_list, n, c->d_dd_flags, c->d_dd_work, wb, c->d_dd_res, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_dd_res, c->d_dd_res, sizeof(DedupResult), hipMemcpyDeviceToHost, c->stream));
+    if (flags) HIPCHK(c, hipMemcpyAsync(flags, c->d_dd_flags, n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(d_flags); (void)hipFree(d_work); (void)hipFree(d_res);
-    if (dups) *dups = r.dups;
+    if (dups) *dups = c->h_dd_res->dups;
     return MKT_OK;
 }
 int mkt_ext_chr_names(mkt_ctx* c, char* out, size_t cap, size_t* len) {
@@ -697,27 +720,36 @@ int mkt_ext_chrstat(mkt_ctx* c, int drop_last, char* out, size_t cap, size_t* le
     *len = 0;
     const uint64_t n = ext_key_count(c, drop_last);
     if (n == 0 || !c->d_chr) return MKT_OK;
-    // the name table -> dense ids in bytewise name order
-    std::vector<unsigned long long> hh(kChrSlots);
-    std::vector<uint8_t> names((size_t)kChrSlots * 64);
-    HIPCHK(c, hipMemcpy(hh.data(), c->d_chr->hash, kChrSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(names.data(), c->d_chr->name, names.size(), hipMemcpyDeviceToHost));
+    // the name table -> dense ids in bytewise name order (through pinned staging: pageable copies cost milliseconds each)
+    const size_t name_bytes = (size_t)kChrSlots * 64, hash_bytes = kChrSlots * sizeof(unsigned long long);
+    if (!c->h_chr_stage) HIPCHK(c, hipHostMalloc((void**)&c->h_chr_stage, hash_bytes + name_bytes + kChrSlots * sizeof(uint16_t), hipHostMallocDefault));
+    unsigned long long* hh = (unsigned long long*)c->h_chr_stage;
+    uint8_t* names = c->h_chr_stage + hash_bytes;
+    uint16_t* dense = (uint16_t*)(c->h_chr_stage + hash_bytes + name_bytes);
+    HIPCHK(c, hipMemcpyAsync(hh, c->d_chr->hash, hash_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(names, c->d_chr->name, name_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     std::vector<std::pair<std::string, uint32_t>> used;
     for (uint32_t s2 = 0; s2 < kChrSlots; ++s2) if (hh[s2]) used.emplace_back(std::string((const char*)&names[(size_t)s2 * 64], names[(size_t)s2 * 64 + 63]), s2);
     std::sort(used.begin(), used.end());
     const uint32_t nd = (uint32_t)used.size();
-    std::vector<uint16_t> dense(kChrSlots, 0);
+    memset(dense, 0, kChrSlots * sizeof(uint16_t));
     for (uint32_t d = 0; d < nd; ++d) dense[used[d].second] = (uint16_t)d;
-    uint16_t* d_dense = nullptr; unsigned long long* d_counts = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d_dense, kChrSlots * sizeof(uint16_t)));
-    HIPCHK(c, hipMalloc((void**)&d_counts, (size_t)nd * nd * sizeof(unsigned long long)));
-    HIPCHK(c, hipMemcpyAsync(d_dense, dense.data(), kChrSlots * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(d_counts, 0, (size_t)nd * nd * sizeof(unsigned long long), c->stream));
-    HIPCHK(c, launch_chrstat(c->d_key_list, n, d_dense, nd, d_counts, c->stream));
-    std::vector<unsigned long long> counts((size_t)nd * nd);
-    HIPCHK(c, hipMemcpyAsync(counts.data(), d_counts, counts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    const size_t cnt_bytes = (size_t)nd * nd * sizeof(unsigned long long);
+    if (!c->d_dense) HIPCHK(c, hipMalloc((void**)&c->d_dense, kChrSlots * sizeof(uint16_t)));
+    if (c->chr_counts_cap < cnt_bytes) {
+        if (c->d_chr_counts) { HIPCHK(c, hipFree(c->d_chr_counts)); HIPCHK(c, hipHostFree(c->h_chr_counts)); }
+        c->d_chr_counts = nullptr; c->h_chr_counts = nullptr; c->chr_counts_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_chr_counts, cnt_bytes));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_chr_counts, cnt_bytes, hipHostMallocDefault));
+        c->chr_counts_cap = cnt_bytes;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_dense, dense, kChrSlots * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_chr_counts, 0, cnt_bytes, c->stream));
+    HIPCHK(c, launch_chrstat(c->d_key_list, n, c->d_dense, nd, c->d_chr_counts, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_chr_counts, c->d_chr_counts, cnt_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(d_dense); (void)hipFree(d_counts);
+    const unsigned long long* counts = c->h_chr_counts;
     std::string txt;
     char num[32];
     for (uint32_t a2 = 0; a2 < nd; ++a2)

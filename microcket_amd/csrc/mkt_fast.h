@@ -85,6 +85,9 @@ struct FastState {
     } u;
     // one bit per line of the window (ballots of the parse / start phases)
     uint64_t m_surv[4], m_eqp[4], m_r1[4], m_r2[4], m_start[4], m_emit[4];
+    // extension: this workgroup's cache of the chromosome table, kept across its tiles.  One word per entry (name bytes
+    // in bits 0..47, table slot in 48..60, valid in 63), so that a lane never pairs one entry's name with another's slot
+    uint64_t cc[64];
     uint32_t NL, first_idx, end_idx, abn, last_line_end, nslot;
     uint32_t cnt[C_COUNT];
     TileSums sums, base;                  // base: ABSOLUTE positions in OutPtrs::pairs / sam / sc
@@ -106,6 +109,23 @@ template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const u
     (void)G;                                          // text offsets of the lean path are head-store offsets
     tv.g = text; tv.n = n; tv.win = st.win; tv.w0 = 0; tv.wlen = Cfg::HW; tv.nlm = nullptr; tv.wsm = nullptr;
     return tv;
+}
+// once per workgroup (kernel) / per state object (emulation)
+template <class Cfg> MKT_HD void fast_init(FastState<Cfg>& st, uint32_t k) { if (k < 64u) st.cc[k] = 0; }
+template <class Cfg> MKT_HD uint32_t fast_chr_slot(FastState<Cfg>& st, ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
+    static_assert(kChrSlots <= 8192, "slot in 13 bits");
+    if (len == 0u || len > 6u) return chr_slot(tab, tv, off, len, err);           // long names: the table itself (hash + probe)
+    // names of up to 6 bytes (chr1 .. chr22, chrX, chrY, chrM, chrEBV): the bytes themselves are the cache key
+    const uint64_t name = ((uint64_t)win_load4(tv, off) | ((uint64_t)win_load4(tv, off + 4u) << 32)) & ((1ull << (8u * len)) - 1ull);
+    // 64 entries, two ways (idx, idx ^ 1): with this multiplier the main chromosomes of hg38 / mm10 / Ensembl naming
+    // (chr1..chr22 chrX chrY chrM, 1..22 X Y MT) all find a place, so after the first tiles every lookup is an LDS hit
+    const uint32_t idx = (uint32_t)((name * 0x9E3779B1ull) >> 30) & 63u;
+    const uint64_t e0 = st.cc[idx], e1 = st.cc[idx ^ 1u];
+    if ((e0 >> 63) && (e0 & 0xFFFFFFFFFFFFull) == name) return (uint32_t)(e0 >> 48) & 8191u;
+    if ((e1 >> 63) && (e1 & 0xFFFFFFFFFFFFull) == name) return (uint32_t)(e1 >> 48) & 8191u;
+    const uint32_t s = chr_slot(tab, tv, off, len, err);
+    st.cc[(e0 >> 63) && !(e1 >> 63) ? (idx ^ 1u) : idx] = name | ((uint64_t)s << 48) | (1ull << 63);
+    return s;
 }
 template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
     st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown; st.nslot = 0;
@@ -351,8 +371,8 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
             TextView tv;
             tv.g = nullptr; tv.n = 0; tv.win = st.win; tv.w0 = 0; tv.wlen = Cfg::HW; tv.nlm = nullptr; tv.wsm = nullptr;
             uint32_t err = 0;
-            const uint32_t sa = chr_slot(out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
-            const uint32_t sb = chr_slot(out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
+            const uint32_t sa = fast_chr_slot(st, out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
+            const uint32_t sb = fast_chr_slot(st, out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
             out.keys[k] = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i]);
             if (err) st.abn = err << 8;
         } else st.abn = E_SC_CAP << 8;

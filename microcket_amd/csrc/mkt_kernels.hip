@@ -424,6 +424,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
 
     __shared__ uint32_t wg_cnt[C_COUNT];                  // this workgroup's share of the block's counters
     if (tid0 < (int)C_COUNT) wg_cnt[tid0] = 0;
+    fast_init(st, (uint32_t)tid0);
     // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         int tid = tid0;

@@ -426,8 +426,7 @@ template <class Cfg> MKT_HD void ph_group(TileState<Cfg>& st, const TextView& tv
 // Slot of a chromosome name in the run's table (claims an empty slot with one 64-bit CAS; no payload is ever read
 // back on the device, so no fences are needed).  Two names are the same chromosome iff their 64-bit FNV-1a agree.
 #if defined(__HIP_DEVICE_COMPILE__)
-MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
-    const uint64_t h = fnv1a64(tv, off, len);
+MKT_HD uint32_t chr_slot_h(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint64_t h, uint32_t* err) {
     uint32_t s = (uint32_t)(h >> 17) & (kChrSlots - 1u);
     for (uint32_t probe = 0; probe < kChrSlots; ++probe) {
         unsigned long long cur = __hip_atomic_load(&tab->hash[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -448,8 +447,7 @@ MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t
     return 0;
 }
 #else
-MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
-    const uint64_t h = fnv1a64(tv, off, len);
+MKT_HD uint32_t chr_slot_h(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint64_t h, uint32_t* err) {
     uint32_t s = (uint32_t)(h >> 17) & (kChrSlots - 1u);
     for (uint32_t probe = 0; probe < kChrSlots; ++probe) {
         if (tab->hash[s] == 0ull) {
@@ -467,6 +465,9 @@ MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t
     return 0;
 }
 #endif
+MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
+    return chr_slot_h(tab, tv, off, len, fnv1a64(tv, off, len), err);
+}
 MKT_HD KeyRec make_key(uint32_t slotA, uint32_t posA, uint32_t slotB, uint32_t posB, bool minusA, bool minusB, uint32_t tile, uint32_t ordinal) {
     KeyRec k;
     k.k0 = ((uint64_t)slotA << 45) | ((uint64_t)slotB << 32) | posA;

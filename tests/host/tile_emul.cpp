@@ -105,6 +105,7 @@ static void emul_block(const uint8_t* text, uint32_t n, const Params& P, std::ve
     res.tiles = nt;
     typedef FastCfg<Cfg::TILE, Cfg::HB, Cfg::HF, FLCAP> FC;
     std::unique_ptr<FastState<FC>> fstp(new FastState<FC>);
+    for (uint32_t k = 0; k < 64; ++k) fast_init(*fstp, k);
     uint64_t lean_ok = 0;
     for (uint32_t t = 0; t < nt; ++t) {
         if (lean && lean_tile<FC>(*fstp, text, n, P, t, out, sc_base, run, tile_groups, res)) { ++lean_ok; continue; }

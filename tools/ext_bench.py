@@ -5,9 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import microcket_amd as m
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
+bg = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 21
 for ext in (0, m.EXT_KEYS):
-    ctx = m.Context("unc", 0.5, 10, False, 8, device=0, tiles=m.TILES_FAST, extensions=ext)
-    ds = ctx.dataset(20260105, 0, pairs, 1 << 20, tail_group=True)
+    ctx = m.Context("unc", 0.5, 10, False, 8, device=0, tiles=m.TILES_AUTO, extensions=ext)
+    ds = ctx.dataset(20260105, 0, pairs, bg, tail_group=True)
     for rep in range(2):
         ctx.reset(); ctx.reset_timing()
         t0 = time.perf_counter()

@@ -6,7 +6,7 @@ code = r'''
 import os, sys
 sys.path.insert(0, %r)
 import microcket_amd as m
-ctx = m.Context("unc", 0.5, 10, False, 8, device=0, tiles=m.TILES_FAST)
+ctx = m.Context("unc", 0.5, 10, False, 8, device=0, tiles=m.TILES_FAST, extensions=m.EXT_KEYS if os.environ.get("MKT_LADDER_EXT") else 0)
 ds = ctx.dataset(20260105, 0, 4000000, 1 << 19)
 for _ in range(2):
     ctx.reset_timing()
