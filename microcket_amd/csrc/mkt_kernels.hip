@@ -874,25 +874,25 @@ uint32_t finish_chunk_tiles() { return NTF; }
 // ---------------------------------------------------------------------------------------------
 // Extension A9: duplicate marking over the run's key list (input order).  A pair is a duplicate when
 // an EARLIER pair has the same (chr1, pos1, chr2, pos2, strand1, strand2).  Hand-written LSD radix
-// sort of (40-bit key hash, index) records -- 4-bit digits, ballot ranking, stable -- then every
-// element looks back inside its equal-hash run for an equal FULL key (exact; hash ties only cost time).
-constexpr int DD_BITS = 40, DD_PASSES = DD_BITS / 4, DD_WG = 256;
+// sort of one u64 per pair, (32-bit key hash << 32 | input index) -- 4-bit digits, ballot ranking,
+// stable -- over only as many hash bits as the pair count needs (log2 n + 2: equal-digit runs then hold
+// 1/4 element on average); every element then looks back inside its run for an equal FULL key (exact;
+// hash ties only cost time, and within a run earlier in memory = earlier in the input).
+constexpr int DD_WG = 256;
 constexpr uint64_t kKeyMask1 = 0xFFFFFFFFC0000000ull;          // posB + the two strand bits of KeyRec::k1
 
 __device__ inline bool key_eq(const KeyRec& x, const KeyRec& y) { return x.k0 == y.k0 && (x.k1 & kKeyMask1) == (y.k1 & kKeyMask1); }
 
-__global__ void k_dd_init(const KeyRec* keys, uint64_t n, uint64_t* h, uint32_t* idx) {
-    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        h[j] = mix64(keys[j].k0 ^ mix64(keys[j].k1 & kKeyMask1)) >> (64 - DD_BITS);
-        idx[j] = (uint32_t)j;
-    }
+__global__ void k_dd_init(const KeyRec* keys, uint64_t n, uint64_t* rec) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
+        rec[j] = (mix64(keys[j].k0 ^ mix64(keys[j].k1 & kKeyMask1)) & 0xFFFFFFFF00000000ull) | j;
 }
-__global__ __launch_bounds__(DD_WG) void k_dd_hist(const uint64_t* h, uint64_t n, uint64_t per, int shift, uint32_t* hist, uint32_t G) {
+__global__ __launch_bounds__(DD_WG) void k_dd_hist(const uint64_t* rec, uint64_t n, uint64_t per, int shift, uint32_t* hist, uint32_t G) {
     __shared__ uint32_t cnt[16];
     if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
-    for (uint64_t j = b + threadIdx.x; j < e; j += DD_WG) atomicAdd(&cnt[(h[j] >> shift) & 15u], 1u);
+    for (uint64_t j = b + threadIdx.x; j < e; j += DD_WG) atomicAdd(&cnt[(rec[j] >> shift) & 15u], 1u);
     __syncthreads();
     if (threadIdx.x < 16) hist[threadIdx.x * G + blockIdx.x] = cnt[threadIdx.x];
 }
@@ -911,8 +911,7 @@ __global__ __launch_bounds__(NT) void k_dd_scan(uint32_t* hist, uint32_t m) {   
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* h, const uint32_t* idx, uint64_t n, uint64_t per, int shift,
-                                                      const uint32_t* hist, uint32_t G, uint64_t* h2, uint32_t* idx2) {
+__global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* rec, uint64_t n, uint64_t per, int shift, const uint32_t* hist, uint32_t G, uint64_t* rec2) {
     __shared__ uint32_t base[16];
     __shared__ uint32_t wcnt[DD_WG / 64][16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -922,9 +921,8 @@ __global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* h, const u
     for (uint64_t j0 = b; j0 < e; j0 += DD_WG) {            // sub-tiles in input order keep the pass stable
         const uint64_t j = j0 + tid;
         const bool live = j < e;
-        const uint64_t hv = live ? h[j] : 0;
-        const uint32_t iv = live ? idx[j] : 0;
-        const uint32_t d = live ? (uint32_t)((hv >> shift) & 15u) : 16u;
+        const uint64_t rv = live ? rec[j] : 0;
+        const uint32_t d = live ? (uint32_t)((rv >> shift) & 15u) : 16u;
         uint32_t rank = 0;
 #pragma unroll
         for (uint32_t dd = 0; dd < 16; ++dd) {
@@ -936,21 +934,26 @@ __global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* h, const u
         if (live) {
             uint32_t o = base[d] + rank;
             for (int w = 0; w < wv; ++w) o += wcnt[w][d];
-            h2[o] = hv; idx2[o] = iv;
+            rec2[o] = rv;
         }
         __syncthreads();
         if (tid < 16) { uint32_t s = 0; for (int w = 0; w < DD_WG / 64; ++w) s += wcnt[w][tid]; base[tid] += s; }
         __syncthreads();
     }
 }
-__global__ void k_dd_mark(const KeyRec* keys, const uint64_t* h, const uint32_t* idx, uint64_t n, uint8_t* flags, DedupResult* res) {
+// run = neighbours that agree on the sorted hash bits; only a full 32-bit hash match loads the other key
+__global__ void k_dd_mark(const KeyRec* keys, const uint64_t* rec, uint64_t n, uint64_t run_mask, uint8_t* flags, DedupResult* res) {
     uint32_t mine = 0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t hv = h[j];
-        const KeyRec me = keys[idx[j]];
+        const uint64_t r = rec[j];
+        const KeyRec me = keys[(uint32_t)r];
         bool dup = false;
-        for (uint64_t b = j; b-- > 0 && h[b] == hv;) if (key_eq(keys[idx[b]], me)) { dup = true; break; }    // earlier in the run = earlier in the input
-        flags[idx[j]] = dup ? 1 : 0;
+        for (uint64_t b = j; b-- > 0;) {
+            const uint64_t o = rec[b];
+            if ((o ^ r) & run_mask) break;                                  // left the run
+            if ((o >> 32) == (r >> 32) && key_eq(keys[(uint32_t)o], me)) { dup = true; break; }    // earlier in the run = earlier in the input
+        }
+        flags[(uint32_t)r] = dup ? 1 : 0;
         mine += dup ? 1u : 0u;
     }
     if (mine) atomicAdd((unsigned long long*)&res->dups, (unsigned long long)mine);
@@ -958,31 +961,33 @@ __global__ void k_dd_mark(const KeyRec* keys, const uint64_t* h, const uint32_t*
 }
 size_t dedup_work_bytes(uint64_t n) {
     const uint64_t G = 1024;
-    return (size_t)(n * (8 + 8 + 4 + 4) + 16 * G * 4 + 4096);
+    return (size_t)(n * (8 + 8) + 16 * G * 4 + 4096);
 }
 hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* work, size_t work_bytes, DedupResult* d_res, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(DedupResult), s);
     if (e != hipSuccess || n == 0) return e;
     if (work_bytes < dedup_work_bytes(n) || n >= (1ull << 32)) return hipErrorInvalidValue;
     uint8_t* w = (uint8_t*)work;
-    uint64_t* hA = (uint64_t*)w; w += n * 8;
-    uint64_t* hB = (uint64_t*)w; w += n * 8;
-    uint32_t* iA = (uint32_t*)w; w += n * 4;
-    uint32_t* iB = (uint32_t*)w; w += n * 4;
+    uint64_t* rA = (uint64_t*)w; w += n * 8;
+    uint64_t* rB = (uint64_t*)w; w += n * 8;
     uint32_t* hist = (uint32_t*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
     uint32_t G = (uint32_t)((n + 8191) / 8192);
     if (G > 1024) G = 1024;
     if (G == 0) G = 1;
     const uint64_t per = (n + G - 1) / G;
-    hipLaunchKernelGGL(k_dd_init, dim3(1024), dim3(256), 0, s, keys, n, hA, iA);
-    for (int p = 0; p < DD_PASSES; ++p) {
-        hipLaunchKernelGGL(k_dd_hist, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)hA, n, per, 4 * p, hist, G);
+    int bits = 2;                                             // log2(n) + 2, in whole digits, 12 .. 32
+    while (bits < 34 && (1ull << (bits - 2)) < n) ++bits;
+    bits = bits < 12 ? 12 : (bits > 32 ? 32 : bits);
+    const int passes = (bits + 3) / 4;
+    hipLaunchKernelGGL(k_dd_init, dim3(1024), dim3(256), 0, s, keys, n, rA);
+    for (int p = 0; p < passes; ++p) {
+        hipLaunchKernelGGL(k_dd_hist, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)rA, n, per, 32 + 4 * p, hist, G);
         hipLaunchKernelGGL(k_dd_scan, dim3(1), dim3(NT), 0, s, hist, 16u * G);
-        hipLaunchKernelGGL(k_dd_scatter, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)hA, (const uint32_t*)iA, n, per, 4 * p, (const uint32_t*)hist, G, hB, iB);
-        uint64_t* th = hA; hA = hB; hB = th;
-        uint32_t* ti = iA; iA = iB; iB = ti;
+        hipLaunchKernelGGL(k_dd_scatter, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)rA, n, per, 32 + 4 * p, (const uint32_t*)hist, G, rB);
+        uint64_t* t = rA; rA = rB; rB = t;
     }
-    hipLaunchKernelGGL(k_dd_mark, dim3(1024), dim3(256), 0, s, keys, (const uint64_t*)hA, (const uint32_t*)iA, n, flags, d_res);
+    const uint64_t run_mask = ((passes * 4 >= 32 ? 0xFFFFFFFFull : ((1ull << (passes * 4)) - 1ull))) << 32;
+    hipLaunchKernelGGL(k_dd_mark, dim3(1024), dim3(256), 0, s, keys, (const uint64_t*)rA, n, run_mask, flags, d_res);
     return hipGetLastError();
 }
 
