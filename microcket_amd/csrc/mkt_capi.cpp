@@ -59,7 +59,8 @@ struct mkt_ctx {
     bool input_done = false, finished = false;
     uint64_t bytes_in = 0, blocks = 0;
     size_t last_n = 0;                   // bytes of the last resident block
-    uint64_t keys_upper = 0;             // upper bound of the key records enqueued so far (extension)
+    double key_density = 0;              // extension: most reported pairs per input byte seen between two syncs (0: nothing seen yet)
+    uint64_t emitted_unfolded = 0;
     uint64_t sc_unfolded = 0;            // self-circle entries of the blocks folded at the last sync (for the density estimate)
     uint64_t bytes_unsynced = 0;         // resident bytes enqueued since the last sync
     // timing
@@ -282,7 +283,10 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
             c->keys_raw_cap = need;
         }
         // the run's list grows by doubling (the stream is idle whenever it has to: growth syncs)
-        const size_t want = (size_t)c->keys_upper + n / 64 + 4096;
+        // room for the records of the blocks in flight: one pair per 64 input bytes until a sync has shown this input's
+        // density, afterwards twice the highest density seen (k_finish checks the real count: too small is an error)
+        const double per_byte = c->key_density > 0 ? (c->key_density * 2 < 1.0 / 64 ? c->key_density * 2 : 1.0 / 64) : 1.0 / 64;
+        const size_t want = (size_t)c->acc.emitted + (size_t)((double)(c->bytes_unsynced + n) * per_byte) + 65536;
         if (c->key_list_cap < want) {
             size_t ncap = c->key_list_cap ? c->key_list_cap * 2 : ((size_t)1 << 22);
             while (ncap < want) ncap *= 2;
@@ -292,7 +296,6 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
             if (c->d_key_list) { HIPCHK(c, hipMemcpy(nl, c->d_key_list, c->key_list_cap * sizeof(KeyRec), hipMemcpyDeviceToDevice)); HIPCHK(c, hipFree(c->d_key_list)); }
             c->d_key_list = nl; c->key_list_cap = ncap;
         }
-        c->keys_upper += n / 64 + 1;
         a.keys_rcap = c->keys_raw_cap / a.nregions;
         a.out.keys = c->d_keys_raw; a.out.keys_cap = c->keys_raw_cap; a.out.chr = c->d_chr;
         a.key_list = c->d_key_list; a.key_list_cap = c->key_list_cap;
@@ -357,8 +360,11 @@ static void note_sc_density(mkt_ctx* c) {
         const double d = (double)c->sc_unfolded / (double)c->bytes_unsynced;
         if (d > c->sc_density) c->sc_density = d;
         if (c->sc_density == 0) c->sc_density = 1e-12;   // seen, none so far
+        const double k = (double)c->emitted_unfolded / (double)c->bytes_unsynced;
+        if (k > c->key_density) c->key_density = k;
+        if (c->key_density == 0) c->key_density = 1e-12;
     }
-    c->sc_unfolded = 0; c->bytes_unsynced = 0;
+    c->sc_unfolded = 0; c->bytes_unsynced = 0; c->emitted_unfolded = 0;
 }
 // entries the next `bytes` of input may add at most, as far as the host can tell: one group per 64 bytes until a sync
 // has shown this input's density, afterwards 4 x the highest density seen and at least one per 65536 bytes.  k_finish
@@ -410,6 +416,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
             HIPCHK(c, hipMalloc((void**)&c->d_sc_tmp, need * kMaxRegions * sizeof(uint64_t)));
             c->sc_tmp_cap = need * kMaxRegions;
             if ((rc = ensure_sc_list(c, (size_t)c->acc.sc + need))) return rc;
+            c->key_density = 0;                // extension: the key list may be what overflowed: back to the worst-case reservation
             grew = true;
         }
         if (!grew) return check_result(c, r);
@@ -417,7 +424,7 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     // fetch outputs
     c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad; adapt_geometry(c, r);
     ++c->blocks;
-    c->sc_unfolded += r.sc; c->bytes_unsynced += n;
+    c->sc_unfolded += r.sc; c->emitted_unfolded += r.emitted; c->bytes_unsynced += n;
     note_sc_density(c);
     size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
     if (c->h_stage.size() < pb + sb) c->h_stage.resize(pb + sb);
@@ -547,7 +554,7 @@ int mkt_sync(mkt_ctx* c) {
         if (r.err) { rc = check_result(c, r); break; }      // fail loudly
         c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
         changed = adapt_geometry(c, r) || changed;
-        c->sc_unfolded += r.sc;
+        c->sc_unfolded += r.sc; c->emitted_unfolded += r.emitted;
         ++c->blocks;
     }
     if (c->res_used > c->res_folded) c->probing = changed;  // a new geometry is checked on one block before queueing ahead
@@ -771,8 +778,8 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
-    c->sc_unfolded = 0; c->bytes_unsynced = 0; c->keys_upper = 0;
-    c->sc_density = 0; c->cfg = c->p.tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST; c->probing = true;      // a new input is probed afresh
+    c->sc_unfolded = 0; c->bytes_unsynced = 0; c->emitted_unfolded = 0;
+    c->sc_density = 0; c->key_density = 0; c->cfg = c->p.tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST; c->probing = true;      // a new input is probed afresh
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;
