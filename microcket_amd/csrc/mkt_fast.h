@@ -409,16 +409,33 @@ template <class Cfg> MKT_HD uint32_t fast_pair_find(const FastState<Cfg>& st, ui
     }
     return lo;
 }
-// byte o of the .pairs line of the group in `slot`
-template <class Cfg> MKT_HD uint8_t fast_layout_byte(const FastState<Cfg>& st, uint32_t slot, uint32_t o) {
+// byte o of the .pairs line of the group in `slot`.  Branch-free: every run, the two literals included, is a byte range of
+// this state object in LDS (the literal words hold their text in memory order), so the byte is ONE load at
+// (start of the run that holds o) + o; picking the run is four selects.
+template <class Cfg> struct FastLayout { uint32_t e0, e1, e2, e3, a0, a1, a2, a3, a4; };
+template <class Cfg> MKT_HD FastLayout<Cfg> fast_layout(const FastState<Cfg>& st, uint32_t slot) {
     const auto& g = st.u.g;
-    const uint32_t e0 = g.l_e0[slot], e1 = g.l_e1[slot], e2 = g.l_e2[slot], e3 = g.l_e3[slot];
-    if (o < e0) return st.win[g.l_qa[slot] + o];
-    if (o < e1) return st.win[g.l_ca[slot] + (o - e0)];
-    if (o < e2) { const uint32_t r = o - e1; return (uint8_t)((r < 8u ? g.l_litA[slot][0] >> (8u * r) : g.l_litA[slot][1] >> (8u * (r - 8u))) & 0xFFu); }
-    if (o < e3) return st.win[g.l_cb[slot] + (o - e2)];
-    const uint32_t r = o - e3;
-    return (uint8_t)((r < 8u ? g.l_litB[slot][0] >> (8u * r) : g.l_litB[slot][1] >> (8u * (r - 8u))) & 0xFFu);
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(&st);
+    const uint32_t w = (uint32_t)(st.win - base);
+    FastLayout<Cfg> L;
+    L.e0 = g.l_e0[slot]; L.e1 = g.l_e1[slot]; L.e2 = g.l_e2[slot]; L.e3 = g.l_e3[slot];
+    L.a0 = w + g.l_qa[slot];                                                                   // state-relative address of byte o, minus o
+    L.a1 = w + g.l_ca[slot] - L.e0;
+    L.a2 = (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litA[slot][0]) - base) - L.e1;
+    L.a3 = w + g.l_cb[slot] - L.e2;
+    L.a4 = (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litB[slot][0]) - base) - L.e3;
+    return L;
+}
+template <class Cfg> MKT_HD uint8_t fast_layout_byte(const FastState<Cfg>& st, const FastLayout<Cfg>& L, uint32_t o) {
+    uint32_t a = L.a0;
+    a = o >= L.e0 ? L.a1 : a;
+    a = o >= L.e1 ? L.a2 : a;
+    a = o >= L.e2 ? L.a3 : a;
+    a = o >= L.e3 ? L.a4 : a;
+    return reinterpret_cast<const uint8_t*>(&st)[(uint32_t)(a + o)];
+}
+template <class Cfg> MKT_HD uint8_t fast_layout_byte(const FastState<Cfg>& st, uint32_t slot, uint32_t o) {
+    return fast_layout_byte(st, fast_layout(st, slot), o);
 }
 // byte k (0 <= k < sums.pair_bytes) of the tile's .pairs output
 template <class Cfg> MKT_HD uint8_t fast_pair_byte(const FastState<Cfg>& st, uint32_t k) {
@@ -442,12 +459,13 @@ template <class Cfg> MKT_HD void fast_own_fill(FastState<Cfg>& st, uint32_t i, u
 // `total` read as 0
 template <class Cfg> MKT_HD uint32_t fast_pair_bytes4(const FastState<Cfg>& st, uint32_t k, uint32_t total, uint32_t ord) {
     const auto& g = st.u.g;
-    uint32_t i = g.em_idx[ord], slot = g.g_slot[i], o = k - g.x_pair[i], plen = g.g_plen[i];
+    uint32_t i = g.em_idx[ord], o = k - g.x_pair[i], plen = g.g_plen[i];
+    FastLayout<Cfg> L = fast_layout(st, g.g_slot[i]);
     uint32_t w = 0;
     for (uint32_t b = 0; b < 4u; ++b) {
         if (k + b >= total) break;
-        if (o >= plen) { ++ord; i = g.em_idx[ord]; slot = g.g_slot[i]; o = 0; plen = g.g_plen[i]; }    // next line (lines are >= 14 bytes)
-        w |= (uint32_t)fast_layout_byte(st, slot, o) << (8u * b);
+        if (o >= plen) { ++ord; i = g.em_idx[ord]; L = fast_layout(st, g.g_slot[i]); o = 0; plen = g.g_plen[i]; }    // next line (lines are >= 14 bytes)
+        w |= (uint32_t)fast_layout_byte(st, L, o) << (8u * b);
         ++o;
     }
     return w;
