@@ -779,7 +779,9 @@ int mkt_reset(mkt_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->acc = RunAccum();
     c->sc_unfolded = 0; c->bytes_unsynced = 0; c->emitted_unfolded = 0;
-    c->sc_density = 0; c->key_density = 0; c->cfg = c->p.tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST; c->probing = true;      // a new input is probed afresh
+    // a new input is probed afresh for its densities; the tile geometry learned on the previous input is where its probe
+    // starts (a context usually sees one kind of data; a fresh context starts from the largest tiles)
+    c->sc_density = 0; c->key_density = 0; c->probing = true;
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;
