@@ -90,6 +90,20 @@ MKT_HD uint32_t popc64(uint64_t x) {
     return (uint32_t)__builtin_popcountll(x);
 #endif
 }
+MKT_HD uint32_t ctz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctz(v);
+#else
+    return (uint32_t)__builtin_ctz(v);
+#endif
+}
+// bit b (0..3) set <-> byte b of w is an ASCII decimal digit (SWAR: no cross-byte carries; one multiply gathers the flags)
+MKT_HD uint32_t digit_bits4(uint32_t w) {
+    const uint32_t y = w & 0x7F7F7F7Fu;
+    const uint32_t ge30 = (y + 0x50505050u) | w, ge3a = (y + 0x46464646u) | w;      // bit 7 of a byte: byte >= '0' / byte > '9'
+    const uint32_t d = ge30 & ~ge3a & 0x80808080u;
+    return (((d >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
 MKT_HD uint32_t ctz64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__ffsll((long long)v) - 1u;
@@ -124,6 +138,11 @@ struct CigarWalk {
     MKT_HD void step(Rec& r, uint8_t c, bool lastChar) {
         if (bad) return;
         if (c >= '0' && c <= '9') { value = value * 10 + (int32_t)(c - '0'); return; }
+        op(r, c, lastChar);
+    }
+    // operation byte c with its count in `value`
+    MKT_HD void op(Rec& r, uint8_t c, bool lastChar) {
+        if (bad) return;
         if (c == 'H' || c == 'S') {
             if (lastChar) r.rclip = value;
             else if (index == 0) r.lclip = value;
@@ -262,11 +281,36 @@ MKT_HD int parse_record_core(const TextView& tv, uint32_t rr, const Params& P, R
     r.mapq = win_parse_uint(tv, rr + ts[4], te[4] + 1u - ts[4], ok);
     CigarWalk cw;
     cw.begin(r);
-    const uint32_t clen = te[5] + 1u - ts[5];
-    for (uint32_t i = 0; i < clen; i += 4u) {
-        uint32_t w = win_load4(tv, rr + ts[5] + i);
-        const uint32_t m = clen - i < 4u ? clen - i : 4u;
-        for (uint32_t b = 0; b < m; ++b) { cw.step(r, (uint8_t)(w & 0xFFu), i + b + 1u == clen); w >>= 8; }
+    const uint32_t cs = rr + ts[5], clen = te[5] + 1u - ts[5];
+    // Per OPERATION instead of per byte when the token is short and every count has at most three digits (reads below
+    // 1000 bp): bit i of `dig` <-> byte i of the token is a decimal digit; each non-digit is an operation whose count is
+    // the digit run before it, read together with the operation byte as one unaligned dword.
+    uint32_t dig = 0;
+    if (clen <= 12u) {
+        dig = digit_bits4(win_load4(tv, cs));
+        if (clen > 4u) dig |= digit_bits4(win_load4(tv, cs + 4u)) << 4;
+        if (clen > 8u) dig |= digit_bits4(win_load4(tv, cs + 8u)) << 8;
+        dig &= (1u << clen) - 1u;
+    }
+    if (clen <= 12u && !(dig & (dig >> 1) & (dig >> 2) & (dig >> 3))) {
+        uint32_t ops = ~dig & ((1u << clen) - 1u);
+        uint32_t run0 = 0;                                          // first byte of the digit run before the next operation
+        while (ops) {
+            const uint32_t p = ctz32(ops);
+            ops &= ops - 1u;
+            const uint32_t L = p - run0;                            // 0..3 digits
+            const uint32_t w = win_load4(tv, cs + p - 3u);          // bytes p-3 .. p: hundreds, tens, units, operation
+            const int32_t value = (int32_t)((L > 0u ? (w >> 16) & 15u : 0u) + (L > 1u ? ((w >> 8) & 15u) * 10u : 0u) + (L > 2u ? (w & 15u) * 100u : 0u));
+            cw.value = value;
+            cw.op(r, (uint8_t)(w >> 24), p + 1u == clen);
+            run0 = p + 1u;
+        }
+    } else {
+        for (uint32_t i = 0; i < clen; i += 4u) {
+            uint32_t w = win_load4(tv, cs + i);
+            const uint32_t m = clen - i < 4u ? clen - i : 4u;
+            for (uint32_t b = 0; b < m; ++b) { cw.step(r, (uint8_t)(w & 0xFFu), i + b + 1u == clen); w >>= 8; }
+        }
     }
     cw.end(r);
     r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;

@@ -561,6 +561,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             st.u.m.hmask[i][c] = (uint16_t)m;
         }
         __syncthreads();
+        STOP_AFTER(9)
 
         // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
         const uint32_t rr_id = ((uint32_t)tid >> 6) < (uint32_t)MKT_RR ? ((uint32_t)tid & 63u) * MKT_RR + ((uint32_t)tid >> 6) : 0xFFFFFFu;
