@@ -536,29 +536,43 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         STOP_AFTER(2)
         // ---- line heads: the eight aligned 16-byte chunks from each line's first byte on (L2 hits: the bytes were
         //      just streamed), with their whitespace bits
-        for (uint32_t it = tid; it < NL * (uint32_t)Cfg::HCH; it += NT) {
-            const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
-            const uint64_t g0 = (uint64_t)G.w0 + (st.goff[i] & ~15u) + (c << 4);
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (g0 < n) {
-                q = *reinterpret_cast<const uint4*>(a.text + g0);
-                if (g0 + 16u > n) {                            // last vector of the block: clear the bytes past the end
-                    const uint32_t keep = (uint32_t)(n - g0);  // 1..15
-                    uint32_t* w = reinterpret_cast<uint32_t*>(&q);
+        {
+            constexpr int HPT = (Cfg::LCAP * Cfg::HCH + NT - 1) / NT;      // chunks per lane
+            uint4 q[HPT];
+#pragma unroll
+            for (int k = 0; k < HPT; ++k) {                                // all loads first ...
+                const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
+                q[k] = make_uint4(0, 0, 0, 0);
+                if (it < NL * (uint32_t)Cfg::HCH) {
+                    const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
+                    const uint64_t g0 = (uint64_t)G.w0 + (st.goff[i] & ~15u) + (c << 4);
+                    if (g0 < n) q[k] = *reinterpret_cast<const uint4*>(a.text + g0);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < HPT; ++k) {                                // ... then the stores and the whitespace bits
+                const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
+                if (it >= NL * (uint32_t)Cfg::HCH) continue;
+                const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
+                const uint64_t g0 = (uint64_t)G.w0 + (st.goff[i] & ~15u) + (c << 4);
+                uint4 x = q[k];
+                if (g0 < n && g0 + 16u > n) {                              // last vector of the block: clear the bytes past the end
+                    const uint32_t keep = (uint32_t)(n - g0);              // 1..15
+                    uint32_t* w = reinterpret_cast<uint32_t*>(&x);
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         const uint32_t lo = (uint32_t)d * 4u;
                         w[d] = keep >= lo + 4u ? w[d] : (keep > lo ? (w[d] & ((1u << ((keep - lo) * 8u)) - 1u)) : 0u);
                     }
                 }
+                {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
+                    uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE + (c << 4)]);
+                    row[0] = x.x; row[1] = x.y; row[2] = x.z; row[3] = x.w;
+                }
+                uint32_t m = pack16(ws_flags(x.x), ws_flags(x.y), ws_flags(x.z), ws_flags(x.w));
+                if (g0 + 16u > n) m &= g0 < n ? (1u << (uint32_t)(n - g0)) - 1u : 0u;       // cleared bytes are not whitespace
+                st.u.m.hmask[i][c] = (uint16_t)m;
             }
-            {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
-                uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE + (c << 4)]);
-                row[0] = q.x; row[1] = q.y; row[2] = q.z; row[3] = q.w;
-            }
-            uint32_t m = pack16(ws_flags(q.x), ws_flags(q.y), ws_flags(q.z), ws_flags(q.w));
-            if (g0 + 16u > n) m &= g0 < n ? (1u << (uint32_t)(n - g0)) - 1u : 0u;       // cleared bytes are not whitespace
-            st.u.m.hmask[i][c] = (uint16_t)m;
         }
         __syncthreads();
         STOP_AFTER(9)
