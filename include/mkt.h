@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 3
+#define MKT_ABI_VERSION 4
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -110,6 +110,12 @@ void mkt_destroy(mkt_ctx* ctx);
  * pointers stay valid until the next call on the context. */
 int mkt_submit(mkt_ctx* ctx, const char* bytes, size_t n, int last);
 int mkt_drain(mkt_ctx* ctx, mkt_out* out);
+/* The same without the intermediate copy: mkt_input_window hands out the free part of the context's pinned input block
+ * (*cap > 0 bytes at *buf; a full block is processed first); the caller reads the next bytes of the SAM stream straight
+ * into it (read / pread, several threads if it likes) and commits them with mkt_submit_window.  Do not mix with
+ * mkt_submit inside one window. */
+int mkt_input_window(mkt_ctx* ctx, char** buf, size_t* cap);
+int mkt_submit_window(mkt_ctx* ctx, size_t n, int last);
 
 /* ---- resident path: text already in HBM (bench.py, multi-GPU shards) --------------------------
  * The block must start on a QNAME-group boundary, end on a line end, be < 2 GiB - 64 KiB and 16-byte

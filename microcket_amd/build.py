@@ -61,7 +61,7 @@ def build_exe(force=False):
     src = os.path.join(CSRC, "sam2pairs_main.cpp")
     if force or _newer(EXE, [src, LIB, os.path.join(ROOT, "include", "mkt.h")]):
         os.makedirs(os.path.dirname(EXE), exist_ok=True)
-        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", EXE, "-L" + HERE, "-lmkt_hip",
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", src, "-o", EXE, "-L" + HERE, "-lmkt_hip",
               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
     return EXE
 

@@ -9,6 +9,7 @@ TILES_AUTO, TILES_FAST, TILES_SMALL = 0, 1, 2
 EXT_KEYS = 1
 EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
+    "mkt_input_window", "mkt_submit_window",
     "mkt_submit", "mkt_drain", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",

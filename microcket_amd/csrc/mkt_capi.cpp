@@ -52,7 +52,7 @@ struct mkt_ctx {
     // host (pinned)
     uint8_t* h_in = nullptr; size_t h_len = 0;
     BlockResult* h_res = nullptr; size_t res_slots = 0, res_used = 0, res_folded = 0;
-    std::vector<uint8_t> h_stage;       // D2H landing for block outputs
+    uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned D2H landing for block outputs (pageable copies pin/unpin per call)
     // streaming outputs
     std::vector<char> out_pairs, out_sam, tail_pairs, tail_sam, drained_pairs, drained_sam;
     RunAccum acc;
@@ -194,6 +194,7 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_syn_sizes) (void)hipFree(c->d_syn_sizes);
     if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_res) (void)hipHostFree(c->h_res);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_sc_logged) (void)hipFree(c->d_sc_logged);
     if (c->h_chr_stage) (void)hipHostFree(c->h_chr_stage);
     if (c->d_dd_flags) (void)hipFree(c->d_dd_flags);
@@ -427,19 +428,25 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     c->sc_unfolded += r.sc; c->emitted_unfolded += r.emitted; c->bytes_unsynced += n;
     note_sc_density(c);
     size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
-    if (c->h_stage.size() < pb + sb) c->h_stage.resize(pb + sb);
+    if (c->h_stage_cap < pb + sb) {
+        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr; c->h_stage_cap = 0;
+        const size_t want = (pb + sb) + (pb + sb) / 4 + 65536;
+        HIPCHK(c, hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault));
+        c->h_stage_cap = want;
+    }
     // gather the region slices: .pairs regions first, then .sam regions; remember where each region landed
     const uint32_t nreg = r.nregions ? r.nregions : 1;
     const size_t prc = (c->pairs_cap / nreg) & ~(size_t)15, src_ = c->P.write_sam ? ((c->sam_cap / nreg) & ~(size_t)15) : 0;
     size_t pstart[kMaxRegions], sstart[kMaxRegions], acc_p = 0, acc_s = pb;
     for (uint32_t q = 0; q < nreg; ++q) {
         pstart[q] = acc_p; sstart[q] = acc_s;
-        if (r.rpair[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + acc_p, c->d_pairs + (size_t)q * prc, (size_t)r.rpair[q], hipMemcpyDeviceToHost, c->stream));
-        if (sb && r.rsam[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage.data() + acc_s, c->d_sam + (size_t)q * src_, (size_t)r.rsam[q], hipMemcpyDeviceToHost, c->stream));
+        if (r.rpair[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage + acc_p, c->d_pairs + (size_t)q * prc, (size_t)r.rpair[q], hipMemcpyDeviceToHost, c->stream));
+        if (sb && r.rsam[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage + acc_s, c->d_sam + (size_t)q * src_, (size_t)r.rsam[q], hipMemcpyDeviceToHost, c->stream));
         acc_p += (size_t)r.rpair[q]; acc_s += sb ? (size_t)r.rsam[q] : 0;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const char* hp = (const char*)c->h_stage.data();
+    const char* hp = (const char*)c->h_stage;
     if (r.last.valid) {
         // the previous newest group is now final: release its bytes; hold back the new newest group's
         // (its bytes sit at [pair_off, +pair_bytes) / [sam_off, +sam_bytes) of this block's outputs)
@@ -460,6 +467,21 @@ static int run_host_block(mkt_ctx* c, size_t n) {
     return MKT_OK;
 }
 
+// the input block is full (or the input ended): run its group-aligned prefix, keep the rest
+static int flush_block(mkt_ctx* c, bool everything) {
+    if (everything) {
+        if (c->h_len) { int rc = run_host_block(c, c->h_len); if (rc) return rc; c->h_len = 0; }
+        return MKT_OK;
+    }
+    const size_t cut = group_aligned_prefix((const char*)c->h_in, c->h_len);
+    if (cut == 0) return fail(c, MKT_E_CAPACITY, "no QNAME-group boundary inside a %zu-byte block: raise block_bytes", c->block_cap);
+    int rc = run_host_block(c, cut);
+    if (rc) return rc;
+    memmove(c->h_in, c->h_in + cut, c->h_len - cut);
+    c->h_len -= cut;
+    return MKT_OK;
+}
+
 int mkt_submit(mkt_ctx* c, const char* bytes, size_t n, int last) {
     if (!c) return MKT_E_ARG;
     if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "submit after the end of input");
@@ -474,19 +496,44 @@ int mkt_submit(mkt_ctx* c, const char* bytes, size_t n, int last) {
         if (take) { memcpy(c->h_in + c->h_len, bytes + pos, take); c->h_len += take; pos += take; }
         const bool all_in = pos == n;
         if (c->h_len == c->block_cap && !(all_in && last)) {
-            size_t cut = group_aligned_prefix((const char*)c->h_in, c->h_len);
-            if (cut == 0) return fail(c, MKT_E_CAPACITY, "no QNAME-group boundary inside a %zu-byte block: raise block_bytes", c->block_cap);
-            int rc = run_host_block(c, cut);
+            int rc = flush_block(c, false);
             if (rc) return rc;
-            memmove(c->h_in, c->h_in + cut, c->h_len - cut);
-            c->h_len -= cut;
             continue;
         }
         if (all_in) break;
     }
     if (last) {
-        if (c->h_len) { int rc = run_host_block(c, c->h_len); if (rc) return rc; c->h_len = 0; }
+        int rc = flush_block(c, true);
+        if (rc) return rc;
         c->input_done = true;
+    }
+    return MKT_OK;
+}
+
+int mkt_input_window(mkt_ctx* c, char** buf, size_t* cap) {
+    if (!c || !buf || !cap) return MKT_E_ARG;
+    if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "input window after the end of input");
+    HIPCHK(c, hipSetDevice(c->p.device));
+    if (!c->h_in) HIPCHK(c, hipHostMalloc((void**)&c->h_in, c->block_cap + 64, hipHostMallocDefault));
+    if (c->h_len == c->block_cap) { int rc = flush_block(c, false); if (rc) return rc; }
+    *buf = (char*)c->h_in + c->h_len;
+    *cap = c->block_cap - c->h_len;
+    return MKT_OK;
+}
+int mkt_submit_window(mkt_ctx* c, size_t n, int last) {
+    if (!c) return MKT_E_ARG;
+    if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "submit after the end of input");
+    if (!c->h_in || n > c->block_cap - c->h_len) return fail(c, MKT_E_ARG, "more bytes than the input window holds");
+    HIPCHK(c, hipSetDevice(c->p.device));
+    c->h_len += n;
+    c->bytes_in += n;
+    if (last) {
+        int rc = flush_block(c, true);
+        if (rc) return rc;
+        c->input_done = true;
+    } else if (c->h_len == c->block_cap) {
+        int rc = flush_block(c, false);
+        if (rc) return rc;
     }
     return MKT_OK;
 }

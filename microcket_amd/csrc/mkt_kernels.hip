@@ -408,7 +408,6 @@ template <class Cfg>
 __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per SIMD: four 36 KB workgroups per CU
     __shared__ FastState<Cfg> st;
     __shared__ ScanScratch scan;
-    __shared__ uint32_t s_tile;
     constexpr int NVEC = (Cfg::W + 15) / 16;
     constexpr int VPT = (NVEC + NT - 1) / NT;
     static_assert(Cfg::LCAP <= NT, "one line per thread in the sums");
@@ -429,7 +428,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
-        if (tid == 0) { s_tile = t; s_out = a.out; fast_reset(st); }
+        if (tid == 0) { s_out = a.out; fast_reset(st); }
         __syncthreads();
         STAMP(0);
         const TileGeom G = fast_geom<Cfg>(t, n);
