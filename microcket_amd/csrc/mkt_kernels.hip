@@ -428,8 +428,9 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
+        // (no barrier: the previous tile ended on one, and nothing below reads what lane 0 resets here before the barrier
+        // that ends the scan phase)
         if (tid == 0) { s_out = a.out; fast_reset(st); }
-        __syncthreads();
         STAMP(0);
         const TileGeom G = fast_geom<Cfg>(t, n);
         const uint32_t wlen = G.w1 - G.w0;
@@ -671,6 +672,10 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             if (own) fast_own_fill(st, i, h);
         }
         __syncthreads();
+        // counters and error bits of the tile are final here; flushed once per workgroup (9 global atomics per TILE on one
+        // cache line would queue up behind each other)
+        if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
+        if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
         {
             if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
                 // one lane per 4-byte-aligned output dword; the partial dwords at both ends go out as bytes
@@ -710,11 +715,8 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                                           // every lane is done with this tile's state
         STAMP(8);
-        if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];        // flushed once per workgroup: 9 global atomics per TILE on one
-        if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);      // cache line would queue up behind each other
-        __syncthreads();
     }
     if (tid0 < (int)C_COUNT && wg_cnt[tid0]) atomicAdd(&a.res->counters[tid0], wg_cnt[tid0]);
 }
