@@ -24,7 +24,7 @@
 #define MKT_LEAN_LCAP kLeanLCAP
 #endif
 #ifndef MKT_LOAD_BATCH
-#define MKT_LOAD_BATCH 5
+#define MKT_LOAD_BATCH 7
 #endif
 
 namespace mkt {
