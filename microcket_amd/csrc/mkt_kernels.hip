@@ -957,20 +957,22 @@ __global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* rec, uint6
         __syncthreads();
     }
 }
-// run = neighbours that agree on the sorted hash bits; only a full 32-bit hash match loads the other key
+// run = neighbours that agree on the sorted hash bits.  Keys are fetched (random 24-byte gathers) only on a full 32-bit
+// hash match with an earlier element of the run, i.e. almost never unless it IS a duplicate; flags start out zeroed.
 __global__ void k_dd_mark(const KeyRec* keys, const uint64_t* rec, uint64_t n, uint64_t run_mask, uint8_t* flags, DedupResult* res) {
     uint32_t mine = 0;
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t r = rec[j];
-        const KeyRec me = keys[(uint32_t)r];
-        bool dup = false;
+        bool dup = false, have = false;
+        KeyRec me;
         for (uint64_t b = j; b-- > 0;) {
             const uint64_t o = rec[b];
             if ((o ^ r) & run_mask) break;                                  // left the run
-            if ((o >> 32) == (r >> 32) && key_eq(keys[(uint32_t)o], me)) { dup = true; break; }    // earlier in the run = earlier in the input
+            if ((o >> 32) != (r >> 32)) continue;
+            if (!have) { me = keys[(uint32_t)r]; have = true; }
+            if (key_eq(keys[(uint32_t)o], me)) { dup = true; break; }       // earlier in the run = earlier in the input
         }
-        flags[(uint32_t)r] = dup ? 1 : 0;
-        mine += dup ? 1u : 0u;
+        if (dup) { flags[(uint32_t)r] = 1; ++mine; }
     }
     if (mine) atomicAdd((unsigned long long*)&res->dups, (unsigned long long)mine);
     if (blockIdx.x == 0 && threadIdx.x == 0) res->total = n;
@@ -1003,6 +1005,8 @@ hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* wo
         uint64_t* t = rA; rA = rB; rB = t;
     }
     const uint64_t run_mask = ((passes * 4 >= 32 ? 0xFFFFFFFFull : ((1ull << (passes * 4)) - 1ull))) << 32;
+    e = hipMemsetAsync(flags, 0, n, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dd_mark, dim3(1024), dim3(256), 0, s, keys, (const uint64_t*)rA, n, run_mask, flags, d_res);
     return hipGetLastError();
 }
