@@ -73,6 +73,8 @@ def load_library():
     L.mkt_destroy.restype = None
     L.mkt_submit.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]
     L.mkt_drain.argtypes = [C.c_void_p, C.POINTER(Out)]
+    L.mkt_input_window.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.mkt_submit_window.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.mkt_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mkt_sync.argtypes = [C.c_void_p]
     L.mkt_fetch_last_block.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -165,6 +167,30 @@ class Context:
             pos += len(part)
             last = pos >= len(text)
             self.submit(part, last)
+            a, b = self.drain()
+            pairs.append(a)
+            sam.append(b)
+            if last:
+                break
+        st = self.finish(True)
+        a, b = self.drain()
+        pairs.append(a)
+        sam.append(b)
+        return b"".join(pairs), b"".join(sam), st, self.format_log(st)
+
+    def run_bytes_window(self, text: bytes, piece=0):
+        """The same through the zero-copy input window (mkt_input_window / mkt_submit_window), `piece` bytes per commit."""
+        pairs, sam = [], []
+        pos = 0
+        while True:
+            buf, cap = C.c_void_p(), C.c_size_t()
+            self._chk(self.L.mkt_input_window(self.h, C.byref(buf), C.byref(cap)), "mkt_input_window")
+            take = min(cap.value, len(text) - pos, piece if piece > 0 else cap.value)
+            if take:
+                C.memmove(buf.value, text[pos:pos + take], take)
+            pos += take
+            last = pos >= len(text)
+            self._chk(self.L.mkt_submit_window(self.h, C.c_size_t(take), 1 if last else 0), "mkt_submit_window")
             a, b = self.drain()
             pairs.append(a)
             sam.append(b)

@@ -89,6 +89,17 @@ def test_ragged_inputs():
         _check(text, "flash", 4, 0.5, 10, True, tiles=m.TILES_SMALL, ordered=True)
 
 
+def test_input_window_equals_submit():
+    """mkt_input_window / mkt_submit_window (what the executable uses) against mkt_submit on the same bytes, odd piece sizes."""
+    _need_gpu()
+    text = util.synth("unc", 11, 4000, tail=1)
+    po, so, lo, ost = util.oracle_run(text, "unc", 4, 0.5, 10, True)
+    for block, piece in ((0, 0), (1 << 16, 0), (1 << 16, 12345), (5000, 777)):
+        with m.Context("unc", 0.5, 10, True, 4, device=0, block_bytes=block, ordered=True) as c:
+            p, s, st, log = c.run_bytes_window(text, piece)
+        assert log == lo and p == po and s == so, (block, piece)
+
+
 def test_tiny_lines_overflow_the_line_table_and_fall_back():
     """Lines of ~35 bytes put more line starts into a window than the fast config's table holds: AUTO re-runs the
     block with the small-tile config; forcing the fast config fails loudly instead of returning wrong results."""
