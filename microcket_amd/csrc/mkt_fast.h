@@ -25,7 +25,7 @@ namespace mkt {
 // bounded by LDS (~193 B per line): the 48 KiB tile fits lines of >= 330 B on average (150 bp reads), the 32 KiB one
 // >= 240 B (100 bp), the 16 KiB one >= 125 B (50 bp).  Under MKT_TILES_AUTO the host starts with the biggest and
 // steps down when a block leaves more than one tile in eight to the generic kernel.
-constexpr int kLeanTile = 49152, kLeanHB = 2048, kLeanHF = 3072, kLeanLCAP = 168;
+constexpr int kLeanTile = 49152, kLeanHB = 3072, kLeanHF = 3072, kLeanLCAP = 168;
 constexpr int kMidTile = 32768, kMidHB = 2048, kMidHF = 3072, kMidLCAP = 160;
 constexpr int kDenseTile = 16384, kDenseHB = 1024, kDenseHF = 2048, kDenseLCAP = 160;
 
