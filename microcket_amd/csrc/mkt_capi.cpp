@@ -307,7 +307,6 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     { const char* e = getenv("MKT_DEBUG_STOP"); a.debug_stop = e ? atoi(e) : 0; }
 #endif
     HIPCHK(c, hipMemsetAsync(c->d_ws, 0, ws_bytes_for(ntiles), c->stream));
-    HIPCHK(c, hipMemsetAsync(a.last_tile, 0xFF, sizeof(int), c->stream));
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
@@ -321,7 +320,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
         HIPCHK(c, hipEventRecord(e1, c->stream));
         KArgs b = a;
         b.use_list = 1; b.ticket = ticket2;
-        HIPCHK(c, launch_tiles(b, cfg, ntiles < 256u ? (int)ntiles : 256, c->stream));
+        HIPCHK(c, launch_tiles(b, cfg, ntiles < 96u ? (int)ntiles : 96, c->stream));
     } else {
         HIPCHK(c, launch_tiles(a, cfg, grid, c->stream));
         HIPCHK(c, hipEventRecord(e1, c->stream));

@@ -733,7 +733,7 @@ __global__ __launch_bounds__(NTF) void k_finish_scan(KArgs a) {
     const uint32_t chunk = blockIdx.x;
     const uint32_t t = chunk * NTF + tid;
     const uint64_t x = t < a.ntiles ? a.tile_groups[t] : 0ull;       // groups | emitted << 32
-    if (t < a.ntiles && a.tile_last[t].valid) atomicMax(a.last_tile, (int)t);
+    if (t < a.ntiles && a.tile_last[t].valid) atomicMax(a.last_tile, (int)t + 1);      // stored + 1: the zeroed workspace means "none"
     uint64_t inc = x;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { uint64_t y = shfl_up64(inc, d); if (lane >= d) inc += y; }
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
             r->pair_bytes = pb; r->emitted = em; r->sam_bytes = sb; r->sc = sc; r->nregions = (uint32_t)a.nregions;
             r->pad = a.defer_count ? *a.defer_count : 0u;         // tiles the lean kernel deferred
             r->tiles = a.ntiles;
-            const int last = *a.last_tile;
+            const int last = *a.last_tile - 1;
             if (last >= 0) r->last = a.tile_last[last];
         }
     }
@@ -794,10 +794,16 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
     if (s_err == 0) {
         // self-circle entries (tile, ordinal) of every region -> global group indices, appended to the run's list
         const uint64_t sc_base = a.run->sc, g_base = a.run->groups;
-        for (int q = 0; q < a.nregions; ++q) {
+        // the workgroups split the regions among themselves (and one region's entries when there are more workgroups than
+        // regions): short independent loops instead of one pass over every region by everybody
+        const int nr = a.nregions;
+        const int parts = (int)gridDim.x >= nr ? (int)gridDim.x / nr : 1;
+        for (int q = (int)blockIdx.x % nr; q < nr; q += (int)gridDim.x) {
+            const int part = (int)blockIdx.x / nr;
+            if (part >= parts) break;
             const uint64_t cnt = s_scpre[q + 1] - s_scpre[q];
             const uint64_t* src = a.out.sc + (uint64_t)q * (a.ordered ? 0 : a.sc_rcap);
-            for (uint64_t k = (uint64_t)blockIdx.x * NTF + tid; k < cnt; k += (uint64_t)gridDim.x * NTF) {
+            for (uint64_t k = (uint64_t)part * NTF + tid; k < cnt; k += (uint64_t)parts * NTF) {
                 const uint64_t e = src[k];
                 a.sc_list[sc_base + s_scpre[q] + k] = g_base + (a.tile_groups[(uint32_t)(e >> 32)] & 0xFFFFFFFFull) + (uint32_t)(e & 0xFFFFFFFFu);
             }

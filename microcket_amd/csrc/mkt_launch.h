@@ -33,7 +33,7 @@ struct KArgs {
     TileLast* tile_last;
     uint32_t* defer_list;       // tiles the lean kernel left to the generic one
     uint32_t* defer_count;
-    int* last_tile;             // highest tile index that opened a group (starts at -1)
+    int* last_tile;             // 1 + highest tile index that opened a group (0: none)
     uint64_t* scan_desc;        // look-back words of k_finish_scan, one per 1024 tiles
     int32_t use_list;           // generic kernel: 1 = walk defer_list[0, *defer_count) instead of all tiles
     BlockResult* res;
