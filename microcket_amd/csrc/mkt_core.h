@@ -358,11 +358,13 @@ template <bool WIN = false>
 MKT_HD bool text_eq(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
     if (alen != blen) return false;
     if (WIN || (tv.inside(a, alen) && tv.inside(b, blen))) {
+        // last dword first: read names of one run share their head and differ in the trailing coordinates
         const uint32_t ra = a - tv.w0, rb = b - tv.w0;
-        for (uint32_t i = 0; i < alen; i += 4u) {
+        for (uint32_t i = alen ? ((alen - 1u) & ~3u) : 0u; alen; i -= 4u) {
             uint32_t x = win_load4(tv, ra + i) ^ win_load4(tv, rb + i);
             if (alen - i < 4u) x &= (1u << ((alen - i) * 8u)) - 1u;
             if (x) return false;
+            if (i == 0u) break;
         }
         return true;
     }
