@@ -31,6 +31,12 @@ def _run(cmd, **kw):
     subprocess.check_call(cmd, **kw)
 
 
+def _headers():
+    """Every header a native artefact may include: csrc/*.h (all of them, so that a new header can never be forgotten) + the ABI."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
         if c and os.path.exists(c):
@@ -40,8 +46,7 @@ def hipcc():
 
 def build_lib(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_capi.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("mkt_core.h", "mkt_tile.h", "mkt_host.h", "mkt_launch.h", "mkt_synth.h")]
-    deps.append(os.path.join(ROOT, "include", "mkt.h"))
+    deps = srcs + _headers()
     if force or _newer(LIB, deps):
         _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function",
               "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", LIB])
@@ -59,7 +64,7 @@ def build_stamps_lib(name="libmkt_hip_stamps.so", defines=("-DMKT_STAMPS",)):
 
 def build_exe(force=False):
     src = os.path.join(CSRC, "sam2pairs_main.cpp")
-    if force or _newer(EXE, [src, LIB, os.path.join(ROOT, "include", "mkt.h")]):
+    if force or _newer(EXE, [src, LIB] + _headers()):
         os.makedirs(os.path.dirname(EXE), exist_ok=True)
         _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", src, "-o", EXE, "-L" + HERE, "-lmkt_hip",
               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
@@ -76,8 +81,7 @@ def build_test_tools():
     os.makedirs(out, exist_ok=True)
     emul = os.path.join(out, "libmkt_emul.so")
     src = os.path.join(ROOT, "tests", "host", "tile_emul.cpp")
-    hdrs = [os.path.join(CSRC, f) for f in ("mkt_core.h", "mkt_tile.h", "mkt_host.h")]
-    if _newer(emul, [src] + hdrs):
+    if _newer(emul, [src] + _headers()):
         _run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-fPIC", "-shared", "-o", emul, src])
     tout = os.path.join(ROOT, "tools", "_build")
     os.makedirs(tout, exist_ok=True)

@@ -249,6 +249,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     a.defer_count = (uint32_t*)(w + 64);
     uint32_t* ticket2 = (uint32_t*)(w + 128);
     a.last_tile = (int*)(w + 192);
+    a.scan_ticket = (uint32_t*)(w + 224);
     w += 256;
     a.scan_desc = (uint64_t*)w; w += 1024 * sizeof(uint64_t);
     if ((ntiles + finish_chunk_tiles() - 1) / finish_chunk_tiles() > 1024) return fail(c, MKT_E_ARG, "block has too many tiles for the finish scan");
@@ -472,7 +473,7 @@ static int flush_block(mkt_ctx* c, bool everything) {
         if (c->h_len) { int rc = run_host_block(c, c->h_len); if (rc) return rc; c->h_len = 0; }
         return MKT_OK;
     }
-    const size_t cut = group_aligned_prefix((const char*)c->h_in, c->h_len);
+    const size_t cut = group_aligned_prefix((const char*)c->h_in, c->h_len, c->P.min_mapq);
     if (cut == 0) return fail(c, MKT_E_CAPACITY, "no QNAME-group boundary inside a %zu-byte block: raise block_bytes", c->block_cap);
     int rc = run_host_block(c, cut);
     if (rc) return rc;

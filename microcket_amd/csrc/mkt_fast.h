@@ -361,7 +361,7 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
     if (counter == C_SELFCIRCLE) {
         uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
         if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
-        else st.abn = E_SC_CAP << 8;                  // reported as an error bit by the kernel
+        else lds_or(&st.abn, E_SC_CAP << 8);          // reported as an error bit by the kernel (OR: other lanes and the claim step set bits too)
     }
     if ((info & GI_EMIT) && out.keys) {               // extension: duplicate-marking key of this pair
         const auto& g = st.u.g;
@@ -374,8 +374,8 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
             const uint32_t sa = fast_chr_slot(st, out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
             const uint32_t sb = fast_chr_slot(st, out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
             out.keys[k] = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i]);
-            if (err) st.abn = err << 8;
-        } else st.abn = E_SC_CAP << 8;
+            if (err) lds_or(&st.abn, err << 8);
+        } else lds_or(&st.abn, E_SC_CAP << 8);
     }
 }
 template <class Cfg> MKT_HD void fast_last(const FastState<Cfg>& st, const TileGeom& G, TileLast* tl, uint32_t i) {

@@ -85,37 +85,82 @@ inline int format_log(const RunStats& s, char* out, size_t cap) {
                     s.counters[C_TRANS], s.counters[C_CIS10K], s.counters[C_CIS1K], s.counters[C_CIS0]);
 }
 
-// Host cut: the largest prefix of buf[0, n) that ends on a line end AND on a QNAME change, so that
-// the next block starts a new group (lines of one read are contiguous in name-grouped SAM).
-// Returns 0 when no such boundary exists inside the buffer.
-inline size_t group_aligned_prefix(const char* buf, size_t n) {
-    auto is_ws_c = [](char c) { return c == ' ' || (c >= 9 && c <= 13); };
-    auto qname = [&](size_t ls, size_t le, size_t* a, size_t* b) {     // first token of [ls, le)
-        size_t p = ls;
-        while (p < le && is_ws_c(buf[p])) ++p;
-        *a = p;
-        while (p < le && !is_ws_c(buf[p])) ++p;
-        *b = p;
-    };
-    if (n == 0) return 0;
+// ---- host cut ----------------------------------------------------------------------------------------
+// The host hands the kernels blocks that start on a QNAME-group boundary.  The reference groups SURVIVING lines only
+// (pairutil.h:157-163 filters on FLAG / MAPQ before it compares names), so the boundary is defined on surviving lines:
+// the carry (what moves to the next block) starts at the first line of the LAST run of surviving lines with equal
+// QNAME.  Filtered lines have no effect on any output and may fall on either side.
+inline bool host_is_ws(char c) { return c == ' ' || (c >= 9 && c <= 13); }
+// first token of the line [ls, le) (le: its '\n' or the end of the bytes)
+inline void host_qname(const char* buf, size_t ls, size_t le, size_t* a, size_t* b) {
+    size_t p = ls;
+    while (p < le && host_is_ws(buf[p])) ++p;
+    *a = p;
+    while (p < le && !host_is_ws(buf[p])) ++p;
+    *b = p;
+}
+// The per-line filter exactly as parse_record (mkt_core.h) applies it: six tokens, decimal FLAG / POS / MAPQ that fit
+// 32 bits, no '@' in front, !(FLAG & 0x700), MAPQ >= min_mapq.
+inline bool host_line_survives(const char* buf, size_t ls, size_t le, uint32_t min_mapq) {
+    if (ls >= le || buf[ls] == '@') return false;
+    size_t p = ls;
+    uint64_t val[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 6; ++k) {
+        while (p < le && host_is_ws(buf[p])) ++p;
+        if (p >= le) return false;                                  // fewer than six tokens
+        const bool num = (k == 1 || k == 3 || k == 4);
+        uint64_t v = 0;
+        while (p < le && !host_is_ws(buf[p])) {
+            if (num) {
+                const unsigned d = (unsigned)(unsigned char)buf[p] - (unsigned)'0';
+                if (d > 9u || v > 0xFFFFFFFFull) return false;
+                v = v * 10 + d;
+            }
+            ++p;
+        }
+        if (num && v > 0xFFFFFFFFull) return false;
+        val[k] = v;
+    }
+    return !(val[1] & 0x700u) && val[4] >= (uint64_t)min_mapq;
+}
+// buf[0, n): returns `cut` with 0 < cut <= end such that buf[0, cut) ends on a line end and the first surviving line at
+// or after `cut` (if any) opens a new group; *end_out = end of the complete lines.  cut == end: no surviving line in the
+// complete lines at all (everything can be processed).  Returns 0 when the complete lines hold a single run (no boundary).
+inline size_t group_aligned_prefix(const char* buf, size_t n, uint32_t min_mapq, size_t* end_out = nullptr) {
     size_t end = n;                                   // exclusive end of complete lines
     while (end > 0 && buf[end - 1] != '\n') --end;
+    if (end_out) *end_out = end;
     if (end == 0) return 0;
-    // last complete line is [ls, end-1)
-    size_t le = end - 1, ls = le;
-    while (ls > 0 && buf[ls - 1] != '\n') --ls;
-    size_t ca, cb;
-    qname(ls, le, &ca, &cb);
-    while (ls > 0) {
-        size_t ple = ls - 1, pls = ple;
-        while (pls > 0 && buf[pls - 1] != '\n') --pls;
-        size_t pa, pb;
-        qname(pls, ple, &pa, &pb);
-        bool same = (pb - pa) == (cb - ca) && memcmp(buf + pa, buf + ca, cb - ca) == 0;
-        if (!same) return ls;                         // cut in front of the last run of equal names
-        ls = pls; ca = pa; cb = pb;
+    bool have = false;
+    size_t ta = 0, tb = 0, tail_ls = end;             // QNAME of the tail run, start of its earliest line seen so far
+    size_t le = end - 1;                              // '\n' of the line under inspection
+    for (;;) {
+        size_t ls = le;
+        while (ls > 0 && buf[ls - 1] != '\n') --ls;
+        if (host_line_survives(buf, ls, le, min_mapq)) {
+            size_t a, b;
+            host_qname(buf, ls, le, &a, &b);
+            if (!have) { have = true; ta = a; tb = b; tail_ls = ls; }
+            else if ((b - a) == (tb - ta) && memcmp(buf + a, buf + ta, b - a) == 0) { ta = a; tb = b; tail_ls = ls; }
+            else return tail_ls;                      // a surviving line with another name: the tail run starts at tail_ls
+        }
+        if (ls == 0) break;
+        le = ls - 1;
     }
-    return 0;
+    return have ? 0 : end;
+}
+// Degenerate inputs (a long stretch of filtered lines behind a surviving one) would make the carry as large as the
+// block: drop the complete lines of carry[0, n) that do not survive (they influence nothing).  Returns the new length.
+inline size_t compact_carry(char* carry, size_t n, uint32_t min_mapq) {
+    size_t w = 0, p = 0;
+    while (p < n) {
+        const char* nl = (const char*)memchr(carry + p, '\n', n - p);
+        if (!nl) { memmove(carry + w, carry + p, n - p); w += n - p; break; }     // the incomplete last line stays
+        const size_t le = (size_t)(nl - carry);
+        if (host_line_survives(carry, p, le, min_mapq)) { memmove(carry + w, carry + p, le + 1 - p); w += le + 1 - p; }
+        p = le + 1;
+    }
+    return w;
 }
 
 }  // namespace mkt

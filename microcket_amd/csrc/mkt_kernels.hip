@@ -179,15 +179,15 @@ __device__ inline uint32_t claim_ranges(const KArgs& a, uint32_t region, const T
     uint32_t err = 0;
     const uint64_t p0 = (uint64_t)region * a.pairs_rcap, s0 = (uint64_t)region * a.sam_rcap, c0 = (uint64_t)region * a.sc_rcap;
     unsigned long long oa = 0, ob = 0;
-    if (sums.pair_bytes | sums.emitted) oa = atomicAdd(&cur->a, (unsigned long long)sums.pair_bytes | ((unsigned long long)sums.emitted << 40));
-    if (sums.sam_bytes | sums.sc) ob = atomicAdd(&cur->b, (unsigned long long)sums.sam_bytes | ((unsigned long long)sums.sc << 40));
-    const uint64_t op = oa & kLow40, os = ob & kLow40, oc = ob >> 40;
+    if (sums.pair_bytes | sums.emitted) oa = atomicAdd(&cur->a, (unsigned long long)sums.pair_bytes | ((unsigned long long)sums.emitted << kCurShift));
+    if (sums.sam_bytes | sums.sc) ob = atomicAdd(&cur->b, (unsigned long long)sums.sam_bytes | ((unsigned long long)sums.sc << kCurShift));
+    const uint64_t op = oa & kCurLow, os = ob & kCurLow, oc = ob >> kCurShift;
     if (op + sums.pair_bytes > a.pairs_rcap) err |= E_PAIRS_CAP;
     if (os + sums.sam_bytes > a.sam_rcap) err |= E_SAM_CAP;
     if (oc + sums.sc > a.sc_rcap) err |= E_SC_CAP;
     base.pair_bytes = (uint32_t)(p0 + op); base.sam_bytes = s0 + os; base.sc = (uint32_t)(c0 + oc);
-    base.emitted = (uint32_t)((uint64_t)region * a.keys_rcap + (oa >> 40));           // extension: slot of the tile's first key record
-    lim.keys_cap = a.keys_rcap ? ((uint64_t)region * a.keys_rcap + ((oa >> 40) + sums.emitted <= a.keys_rcap ? a.keys_rcap : 0)) : 0;
+    base.emitted = (uint32_t)((uint64_t)region * a.keys_rcap + (oa >> kCurShift));           // extension: slot of the tile's first key record
+    lim.keys_cap = a.keys_rcap ? ((uint64_t)region * a.keys_rcap + ((oa >> kCurShift) + sums.emitted <= a.keys_rcap ? a.keys_rcap : 0)) : 0;
     region_pair0 = (uint32_t)p0; region_sam0 = (uint32_t)s0;
     lim.pairs_cap = err & E_PAIRS_CAP ? 0 : p0 + a.pairs_rcap;     // an overflowing tile writes nothing
     lim.sam_cap = err & E_SAM_CAP ? 0 : s0 + a.sam_rcap;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             const uint32_t lead = G.w0 == 0 ? 1u : 0u;
             const uint32_t NL = (uint32_t)total + lead;
             if (NL > (uint32_t)Cfg::LCAP) {
-                if (tid == 0) { st.err |= E_LINE_TABLE; st.NL = 0; st.first_idx = 0; st.end_idx = 0; }
+                if (tid == 0) { lds_or(&st.err, E_LINE_TABLE); st.NL = 0; st.first_idx = 0; st.end_idx = 0; }
             } else {
                 uint32_t idx = (uint32_t)ex + lead;
                 for (uint32_t k = 0; k < (uint32_t)VPT; ++k) {
@@ -358,13 +358,13 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
                 uint64_t ex = lookback(a.descC, t, st.sums.sam_bytes, &a.res->err);
                 if ((tid & 63) == 0) st.base.sam_bytes = ex;
             } else if (tid == 192) {      // totals (k_finish reads them from the region cursors in both modes)
-                if (st.sums.pair_bytes | st.sums.emitted) atomicAdd(&a.cur[0].a, (unsigned long long)st.sums.pair_bytes | ((unsigned long long)st.sums.emitted << 40));
-                if (st.sums.sam_bytes | st.sums.sc) atomicAdd(&a.cur[0].b, (unsigned long long)st.sums.sam_bytes | ((unsigned long long)st.sums.sc << 40));
+                if (st.sums.pair_bytes | st.sums.emitted) atomicAdd(&a.cur[0].a, (unsigned long long)st.sums.pair_bytes | ((unsigned long long)st.sums.emitted << kCurShift));
+                if (st.sums.sam_bytes | st.sums.sc) atomicAdd(&a.cur[0].b, (unsigned long long)st.sums.sam_bytes | ((unsigned long long)st.sums.sc << kCurShift));
             }
         } else if (tid == 0) {
             const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
             st.region_id = region;
-            if (e) st.err |= e;
+            if (e) lds_or(&st.err, e);
         }
         if (tid == 5) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
         __syncthreads();
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             const uint32_t total = st.sums.pair_bytes;
             const uint64_t go = st.base.pair_bytes;
             if (go + total <= s_out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) s_out.pairs[go + k] = tile_pair_byte(st, tv, k); }
-            else if (tid == 0 && total) st.err |= E_PAIRS_CAP;
+            else if (tid == 0 && total) lds_or(&st.err, E_PAIRS_CAP);
         }
         if (P.write_sam) {   // contiguous groups: straight byte-range copies
             for (uint32_t i = first_idx; i < end_idx; ++i) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
                 const uint32_t len = st.u.g.g_slen[i], src = st.off[i];
                 const uint64_t go = st.base.sam_bytes + st.u.g.x_sam[i];
                 if (go + len <= s_out.sam_cap) { for (uint32_t k = tid; k < len; k += NT) s_out.sam[go + k] = tv.at(src + k); }
-                else if (tid == 0) st.err |= E_SAM_CAP;
+                else if (tid == 0) lds_or(&st.err, E_SAM_CAP);
             }
         }
         __syncthreads();
@@ -654,7 +654,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         if (tid == 0) {
             const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
             st.region_id = region;
-            if (e) st.abn |= e << 8;
+            if (e) lds_or(&st.abn, e << 8);
         } else if (tid == 4) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
         __syncthreads();
         STAMP(7);
@@ -729,8 +729,13 @@ constexpr int NTF = 1024;
 __global__ __launch_bounds__(NTF) void k_finish_scan(KArgs a) {
     __shared__ uint64_t s_wave[NTF / 64];
     __shared__ uint64_t s_pre;
+    __shared__ uint32_t s_chunk;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t chunk = blockIdx.x;
+    // chunks are handed out by ticket, in the order workgroups actually start: a chunk only ever waits (look-back) for
+    // chunks whose workgroups are already running, whatever the dispatch order of blockIdx
+    if (tid == 0) s_chunk = atomicAdd(a.scan_ticket, 1u);
+    __syncthreads();
+    const uint32_t chunk = s_chunk;
     const uint32_t t = chunk * NTF + tid;
     const uint64_t x = t < a.ntiles ? a.tile_groups[t] : 0ull;       // groups | emitted << 32
     if (t < a.ntiles && a.tile_last[t].valid) atomicMax(a.last_tile, (int)t + 1);      // stored + 1: the zeroed workspace means "none"
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
         uint32_t err = 0;
         for (int q = 0; q < a.nregions; ++q) {
             const uint64_t ca = s_ca[q], cb = s_cb[q];
-            const uint64_t p = ca & kLow40, e = ca >> 40, sm = cb & kLow40, c = cb >> 40;
+            const uint64_t p = ca & kCurLow, e = ca >> kCurShift, sm = cb & kCurLow, c = cb >> kCurShift;
             if (blockIdx.x == 0) { r->rpair[q] = p; r->rsam[q] = sm; }
             s_scpre[q] = sc;
             pb += p; em += e; sb += sm; sc += c;
@@ -820,7 +825,7 @@ __global__ void k_keys_place(KArgs a) {
     if (r->err) return;
     const uint64_t base = a.run->emitted;
     for (int q = 0; q < a.nregions; ++q) {
-        const uint64_t cnt = a.cur[q].a >> 40;
+        const uint64_t cnt = a.cur[q].a >> kCurShift;
         const KeyRec* src = a.out.keys + (uint64_t)q * (a.ordered ? 0 : a.keys_rcap);
         for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (uint64_t)gridDim.x * blockDim.x) {
             KeyRec rec = src[k];

@@ -14,10 +14,13 @@ enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2, CFG_MID = 3 };      // tile g
 struct DevRun { uint64_t groups, sc, emitted; };
 
 // One output region's cursors, alone on a 128-byte line so that the per-tile atomics of different
-// regions never meet.  a: .pairs bytes (low 40 bits) | emitted lines (high 24); b: .sam bytes | self-circles.
+// regions never meet.  a: .pairs bytes (low 36 bits) | emitted lines (high 28); b: .sam bytes | self-circles.
+// A block is < 2 GiB of text and both outputs are shorter than their input, so 36 bits hold any byte count; a reported
+// pair or self-circle needs a group of >= 12 input bytes, so 2^28 lines cannot be exceeded inside one block either.
 struct alignas(128) RegionCur { unsigned long long a, b; unsigned long long pad[14]; };
 constexpr int kMaxRegions = 16;
-constexpr unsigned long long kLow40 = (1ull << 40) - 1ull;
+constexpr int kCurShift = 36;
+constexpr unsigned long long kCurLow = (1ull << kCurShift) - 1ull;
 
 struct KArgs {
     const uint8_t* text;        // block text, 16-byte aligned
@@ -35,6 +38,7 @@ struct KArgs {
     uint32_t* defer_count;
     int* last_tile;             // 1 + highest tile index that opened a group (0: none)
     uint64_t* scan_desc;        // look-back words of k_finish_scan, one per 1024 tiles
+    uint32_t* scan_ticket;      // ... and the ticket that hands its chunks out
     int32_t use_list;           // generic kernel: 1 = walk defer_list[0, *defer_count) instead of all tiles
     BlockResult* res;
     DevRun* run;

@@ -130,12 +130,25 @@ template <class Cfg> MKT_HD void tile_reset(TileState<Cfg>& st) {
     for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
 }
 
+// LDS read-modify-write helpers (atomics in the kernels, plain in the serial host emulation)
+#if defined(__HIP_DEVICE_COMPILE__)
+MKT_HD uint32_t lds_inc(uint32_t* p) { return atomicAdd(p, 1u); }
+MKT_HD void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
+MKT_HD void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+MKT_HD void lds_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
+#else
+MKT_HD uint32_t lds_inc(uint32_t* p) { return (*p)++; }
+MKT_HD void lds_add(uint32_t* p, uint32_t v) { *p += v; }
+MKT_HD void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+MKT_HD void lds_or64(uint64_t* p, uint64_t v) { *p |= v; }
+#endif
+
 MKT_HD bool rec_in_range(const Rec& r) { return r.qn_off <= 0xFFFFu && r.qn_len <= 0xFFFFu && r.rn_off <= 0xFFFFu && r.rn_len <= 0xFFFFu; }
 
 template <class Cfg> MKT_HD bool store_rec(TileState<Cfg>& st, uint32_t idx, const Rec& r) {
     bool s = r.survive;
     if (!rec_in_range(r)) {
-        if (s) st.err |= E_FIELD_RANGE;     // benign race: every writer ORs the same bit
+        if (s) lds_or(&st.err, E_FIELD_RANGE);
         s = false;
     }
     st.off[idx] = r.off; st.pos[idx] = r.pos;
@@ -307,17 +320,6 @@ template <class Cfg> MKT_HD bool is_start(const TileState<Cfg>& st, const TextVi
 }
 
 // ---- phase: walk the group opened by line i, classify it ---------------------------------------
-#if defined(__HIP_DEVICE_COMPILE__)
-MKT_HD uint32_t lds_inc(uint32_t* p) { return atomicAdd(p, 1u); }
-MKT_HD void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
-MKT_HD void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
-MKT_HD void lds_or64(uint64_t* p, uint64_t v) { atomicOr((unsigned long long*)p, (unsigned long long)v); }
-#else
-MKT_HD uint32_t lds_inc(uint32_t* p) { return (*p)++; }
-MKT_HD void lds_add(uint32_t* p, uint32_t v) { *p += v; }
-MKT_HD void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
-MKT_HD void lds_or64(uint64_t* p, uint64_t v) { *p |= v; }
-#endif
 
 struct GroupWalk {
     uint32_t nmem, n1, n2;

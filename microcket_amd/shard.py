@@ -20,30 +20,66 @@ def _first_token(buf, ls):
     return buf[ls:e]
 
 
-def cut_points(buf: bytes, parts: int):
-    """Byte offsets [0, c1, ..., len] cutting `buf` into `parts` ranges that start on a line whose
-    QNAME differs from the previous line's (lines of one read are contiguous in name-grouped SAM)."""
+def _survives(buf, ls, min_mapq):
+    """The per-line filter of pairutil.h:157-161 on the line starting at ls: six tokens, decimal FLAG / POS / MAPQ,
+    not FLAG & 0x700, MAPQ >= min_mapq (a header line never survives)."""
+    nl = buf.find(b"\n", ls)
+    tok = buf[ls:nl if nl >= 0 else len(buf)].split(None, 6)
+    if len(tok) < 6 or tok[0][:1] == b"@":
+        return False
+    try:
+        if not (tok[1].isdigit() and tok[3].isdigit() and tok[4].isdigit()):
+            return False
+        flag, pos, mapq = int(tok[1]), int(tok[3]), int(tok[4])
+    except ValueError:
+        return False
+    if flag > 0xFFFFFFFF or pos > 0xFFFFFFFF or mapq > 0xFFFFFFFF:
+        return False
+    return not (flag & 0x700) and mapq >= min_mapq
+
+
+def cut_points(buf: bytes, parts: int, min_mapq=None):
+    """Byte offsets [0, c1, ..., len] cutting `buf` into `parts` ranges, each starting on a line that opens a QNAME group.
+
+    The reference groups SURVIVING lines only (pairutil.h:157-163 filters before it compares names), so a cut is valid
+    when the last surviving line before it and the first surviving line after it carry different names.  With
+    min_mapq=None the raw names of adjacent lines are compared instead, which is the same thing for name-grouped
+    aligner output (lines of one read contiguous)."""
     n = len(buf)
+
+    def line_after(p):
+        nl = buf.find(b"\n", p)
+        return n if nl < 0 else nl + 1
+
+    def valid(p):
+        if p <= 0 or p >= n:
+            return True
+        if min_mapq is None:
+            prev_ls = buf.rfind(b"\n", 0, p - 1) + 1
+            return _first_token(buf, prev_ls) != _first_token(buf, p)
+        q = p                                           # last surviving line before p
+        prev = None
+        while q > 0:
+            ls = buf.rfind(b"\n", 0, q - 1) + 1
+            if _survives(buf, ls, min_mapq):
+                prev = _first_token(buf, ls)
+                break
+            q = ls
+        if prev is None:
+            return True
+        q = p                                           # first surviving line at or after p
+        while q < n:
+            if _survives(buf, q, min_mapq):
+                return _first_token(buf, q) != prev
+            q = line_after(q)
+        return True
+
     cuts = [0]
     for k in range(1, parts):
         p = max(cuts[-1], n * k // parts)
-        nl = buf.find(b"\n", p)
-        if nl < 0:
-            p = n
-        else:
-            p = nl + 1
-            prev_ls = buf.rfind(b"\n", 0, nl) + 1
-            prev = _first_token(buf, prev_ls)
-            while p < n:
-                cur = _first_token(buf, p)
-                if cur != prev:
-                    break
-                nl = buf.find(b"\n", p)
-                if nl < 0:
-                    p = n
-                    break
-                prev = cur
-                p = nl + 1
+        p = line_after(p) if p > 0 else 0
+        while p < n and not valid(p):
+            p = line_after(p)
         cuts.append(min(p, n))
     cuts.append(n)
     return cuts

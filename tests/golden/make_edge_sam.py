@@ -1,6 +1,6 @@
 """Hand-written edge-case SAM inputs (one record group per branch of the reference's classifiers).
 
-Writes edge_unc.sam and edge_flash.sam next to this script.  Deterministic, no randomness.
+Writes edge_unc.sam, edge_flash.sam and edge_aba.sam next to this script.  Deterministic, no randomness.
 Branches follow SURVEY.md 3.4 / 3.5; comments name the reference lines each group exercises.
 """
 import os
@@ -111,6 +111,25 @@ def unc():
     return "".join(L)
 
 
+def aba():
+    """Input that is NOT name-grouped line by line: a filtered line with another name sits inside a group (A kept, B filtered,
+    A kept).  The reference filters before it compares names (pairutil.h:157-163), so A's two lines are ONE group; a block or
+    shard cut between A and B must not split it (the host cut of mkt_host.h works on surviving lines)."""
+    L = []
+    a = L.append
+    for g in range(40):
+        q = f"aba{g:03d}"
+        a(rec(q, 65, "chr1", 1000 + 17 * g, 60, "150M"))
+        for k in range(g % 3 + 1):                                                    # 1..3 filtered strangers in between
+            a(rec(f"stranger{g:03d}_{k}", 129 if k % 2 else 65, "chr2", 5000 + g, 0 if k != 1 else 60, "150M") if k != 1
+              else rec(f"stranger{g:03d}_{k}", 129 + 256, "chr2", 5000 + g, 60, "150M"))    # MAPQ 0 / secondary (0x100): both filtered
+        a(rec(q, 129, "chr1", 90000 + 31 * g, 60, "150M"))
+        if g % 5 == 0:                                                                # a plain group in between
+            a(rec(f"plain{g:03d}", 65, "chr3", 100 + g, 60, "150M"))
+            a(rec(f"plain{g:03d}", 129, "chr3", 70000 + g, 60, "150M"))
+    return "".join(L)
+
+
 def flash():
     L = []
     a = L.append
@@ -159,4 +178,5 @@ def flash():
 if __name__ == "__main__":
     open(os.path.join(HERE, "edge_unc.sam"), "w").write(unc())
     open(os.path.join(HERE, "edge_flash.sam"), "w").write(flash())
+    open(os.path.join(HERE, "edge_aba.sam"), "w").write(aba())
     print("written")

@@ -25,7 +25,14 @@ SYNTH = [  # (name, profile, seed, groups, read_len, genome, lanes)
     ("flash", "flash", 20260105, 5000, 150, "hg38", 1),
     ("stress", "stress", 20260106, 12000, 150, "hg38", 1),
     ("unc100_mm10_4lanes", "unc", 20260108, 5000, 100, "mm10", 4),
+    # BASELINE configs C4 / C5 at sizes that leave the 48 KiB geometry (several blocks, line tables of the 32 / 16 KiB lean
+    # kernels): the reference's own outputs pin those kernels.  One case each (big inputs: seconds of reference time).
+    ("unc100_hg38_300k", "unc", 20260109, 300000, 100, "hg38", 1),
+    ("unc100_mm10_4lanes_300k", "unc", 20260110, 300000, 100, "mm10", 4),
+    ("unc60_hg38_300k", "unc", 20260111, 300000, 60, "hg38", 1),
+    ("stress100_hg38_200k", "stress", 20260112, 200000, 100, "hg38", 1),
 ]
+BIG_GRID = [(8, 0.5, 10, True)]
 
 
 def case(text, mode, T, ratio, mapq, sam, full):
@@ -42,7 +49,7 @@ def case(text, mode, T, ratio, mapq, sam, full):
 def main():
     assert util.have_ref(), "oracle/_ref/sam2pairs.ref missing: run make -C oracle (needs /root/reference)"
     out = {"generator": "tests/golden/make_golden.py", "reference_build": "g++ -std=c++11 -O3 -fopenmp (makefile:3,13-15)", "inputs": []}
-    for name in ("edge_unc.sam", "edge_flash.sam"):
+    for name in ("edge_unc.sam", "edge_flash.sam", "edge_aba.sam"):
         text = open(os.path.join(HERE, name), "rb").read()
         ent = {"name": name, "kind": "file", "sha256": util.sha(text), "cases": []}
         for mode in ("unc", "flash"):
@@ -55,7 +62,7 @@ def main():
                "sha256": util.sha(text), "bytes": len(text), "cases": []}
         modes = ("flash",) if prof == "flash" else ("unc",) if prof == "unc" else ("unc", "flash")
         for mode in modes:
-            for (T, ratio, mapq, sam) in GRID:
+            for (T, ratio, mapq, sam) in (BIG_GRID if groups > 100000 else GRID):
                 ent["cases"].append(case(text, mode, T, ratio, mapq, sam, False))
         out["inputs"].append(ent)
     with open(os.path.join(HERE, "golden.json"), "w") as f:

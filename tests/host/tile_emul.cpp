@@ -202,7 +202,7 @@ static void emul_feed(EmulShard& S, const char* text, size_t n, size_t block_byt
         if (pos + take < n) {                      // not the final block: cut on a group boundary
             size_t span = take;
             for (;;) {
-                size_t cut = group_aligned_prefix(text + pos, span);
+                size_t cut = group_aligned_prefix(text + pos, span, S.P.min_mapq);
                 if (cut) { take = cut; break; }
                 if (pos + span >= n) { take = n - pos; break; }
                 span = (span * 2 < n - pos) ? span * 2 : n - pos;

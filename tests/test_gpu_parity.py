@@ -40,7 +40,9 @@ def _check(text, mode, T, ratio, mapq, sam, **kw):
 
 
 def test_golden_vectors_through_the_c_abi(golden):
-    """Every golden vector (outputs of the reference itself) reproduced by the HIP path."""
+    """Every golden vector (outputs of the reference itself) reproduced by the HIP path.  The big entries (BASELINE configs
+    C4 / C5 shapes: 100 bp hg38, mm10 with 4 lanes, 60 bp; >= 2^18 groups) run in 24 MiB blocks so that MKT_TILES_AUTO
+    leaves the 48 KiB geometry: the reference's own outputs pin the 32 KiB and 16 KiB lean kernels byte for byte."""
     _need_gpu()
     for ent in golden["inputs"]:
         if ent["kind"] == "file":
@@ -48,13 +50,45 @@ def test_golden_vectors_through_the_c_abi(golden):
         else:
             text = util.synth(ent["profile"], ent["seed"], ent["groups"], ent["read_len"], ent["genome"], ent["lanes"], 1)
         assert util.sha(text) == ent["sha256"]
+        big = ent["kind"] == "synth" and ent["groups"] > 100000
         for c in ent["cases"]:
-            p, s, stats, log = _run(text, c["mode"], c["threads"], c["ratio"], c["mapq"], c["sam"])
+            with m.Context(c["mode"], c["ratio"], c["mapq"], c["sam"], c["threads"], device=0, block_bytes=(24 << 20) if big else 0) as ctx:
+                p, s, stats, log = ctx.run_bytes(text, chunk=(16 << 20) if big else (1 << 20))
+                tm = ctx.timing()
             cp, cs = util.canon(p), util.canon(s)
             tag = (ent["name"], c["mode"], c["threads"], c["ratio"], c["mapq"], c["sam"])
             assert log.decode() == c["log"], tag
             assert util.sha(cp) == c["pairs_sha256"] and cp.count(b"\n") == c["pairs_lines"], tag
             assert util.sha(cs) == c["sam_sha256"], tag
+            if big:     # the lean kernel of the stepped-down geometry did the work, not the generic one
+                assert tm.tiles > 0 and tm.deferred_tiles * 3 < tm.tiles, (tag, tm.tiles, tm.deferred_tiles)
+
+
+@pytest.mark.parametrize("read_len", [100, 60])
+@pytest.mark.parametrize("profile,pid,modes", [("unc", 0, ("unc",)), ("stress", 2, ("unc", "flash")), ("flash", 1, ("flash",))])
+def test_lean_geometries_byte_parity(profile, pid, modes, read_len):
+    """The production kernels for 100 bp (32 KiB tiles) and 50-75 bp reads (16 KiB tiles): >= 2^18 groups through the
+    streaming path in 48 MiB blocks under MKT_TILES_AUTO; .log byte-identical, .pairs and .sam equal to the oracle's as line
+    multisets (same length + order-independent 64-bit checksum of the lines), few tiles left to the generic kernel."""
+    _need_gpu()
+    groups = (1 << 18) + (1 << 16) + 4321
+    with m.Context("unc", device=0) as c:
+        ds = c.dataset(777 + pid, pid, groups, 1 << 17, read_len=read_len, genome=(pid == 2), lanes=1, tail_group=True)
+        host = b"".join(c.copy_to_host(p, nb) for (p, nb, g) in ds.blocks)
+        ds.close()
+    for mode in modes:
+        for sam in (True, False):
+            po, so, lo, ost = util.oracle_run(host, mode, 8, 0.5, 10, sam)
+            with m.Context(mode, 0.5, 10, sam, 8, device=0, block_bytes=48 << 20) as c:
+                p, s, st, log = c.run_bytes(host, chunk=32 << 20)
+                tm = c.timing()
+            tag = (profile, mode, read_len, sam, tm.tiles, tm.deferred_tiles)
+            assert log == lo, tag
+            assert st.groups == ost.groups and st.pairs == ost.pairs, tag
+            assert len(p) == len(po) and _line_multiset_checksum(p) == _line_multiset_checksum(po), tag
+            assert len(s) == len(so) and _line_multiset_checksum(s) == _line_multiset_checksum(so), tag
+            if profile != "flash":       # flash lines are long whatever the read length: they stay on the 48 KiB tiles
+                assert tm.deferred_tiles * 3 < tm.tiles, tag
 
 
 @pytest.mark.parametrize("tiles,ordered", [(m.TILES_FAST, True), (m.TILES_FAST, False), (m.TILES_SMALL, True)])
@@ -70,7 +104,7 @@ def test_synthetic_sets_vs_oracle(profile, seed, groups, modes, tiles, ordered):
                 _check(text, mode, T, ratio, mapq, sam, tiles=tiles, ordered=ordered, block=block, chunk=70001)
 
 
-@pytest.mark.parametrize("name", ["edge_unc.sam", "edge_flash.sam"])
+@pytest.mark.parametrize("name", ["edge_unc.sam", "edge_flash.sam", "edge_aba.sam"])
 def test_edge_fixtures_vs_oracle(name):
     _need_gpu()
     text = open(os.path.join(util.GOLDEN, name), "rb").read()

@@ -49,6 +49,36 @@ def test_tile_phases_synthetic(profile, seed, groups, modes, cfg):
                 _check(text, mode, T, ratio, mapq, sam, cfg, block)
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 3, 10, 13])
+def test_filtered_stranger_inside_a_group_never_splits_it(cfg):
+    """A kept, B filtered, A kept (tests/golden/edge_aba.sam): the reference groups surviving lines only, so the host cut
+    must not fall between A and B whatever the block size."""
+    text = open(os.path.join(util.GOLDEN, "edge_aba.sam"), "rb").read()
+    for (T, ratio, mapq, sam) in ((4, 0.5, 10, True), (8, 0.5, 1, False)):
+        for block in (0, 700, 1500, 4096, 20000):
+            _check(text, "unc", T, ratio, mapq, sam, cfg, block)
+    _check(text, "flash", 4, 0.5, 10, True, cfg, 1500)
+
+
+def test_host_cut_on_surviving_lines():
+    from microcket_amd import shard
+    text = open(os.path.join(util.GOLDEN, "edge_aba.sam"), "rb").read()
+    po, so, lo, st = util.oracle_run(text, "unc", 4, 0.5, 10, True)
+    for parts in (2, 3, 7):
+        cuts = shard.cut_points(text, parts, min_mapq=10)
+        pairs = b""
+        groups = 0
+        for r in range(parts):
+            piece = text[cuts[r]:cuts[r + 1]]
+            # every piece is a whole number of groups: its own oracle run + a sacrificial last group = the same lines
+            p, s_, l_, st_ = util.oracle_run(piece + b"zz\t65\tchr1\t1\t60\t1M\nzz\t129\tchr1\t1\t60\t1M\n", "unc", 4, 0.5, 10, True)
+            pairs += p
+            groups += st_.groups - 1
+        assert groups == st.groups, (parts, groups, st.groups)
+        assert util.canon(pairs).count(b"\n") >= util.canon(po).count(b"\n")      # the whole input's last group is dropped (Q1), the pieces' are not
+        assert set(po.splitlines()) <= set(pairs.splitlines())
+
+
 def test_ragged_and_empty_inputs():
     for text in (b"", b"\n", b"\n\n\n", b"@HD\tVN:1.6\n", b"no newline at all", b"a\tb\n",
                  b"r1\t65\tchr1\t100\t60\t50M\t=\t1\t0\tAC\tFF\nr1\t129\tchr1\t5000\t60\t50M\t=\t1\t0\tAC\tFF\nr2\t65\tchr1\t1\t60\t5M"):

@@ -16,16 +16,23 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODES = {"flash": 0, "unc": 1}
 
 
+_built_once = False
+
+
 def ensure_built():
     """Builds the CPU-side test tools (oracle, emulation, generator) if missing."""
-    need = [ORACLE_SO, ORACLE_EXE, EMUL_SO, SYNTH_EXE]
-    if all(os.path.exists(p) for p in need):
+    global _built_once
+    if _built_once:
         return
     import sys
     sys.path.insert(0, ROOT)
     from microcket_amd import build
+    # mtime-checked (make / build._newer): an edited header rebuilds the emulation and the oracle instead of testing stale code
     build.build_oracle()
     build.build_test_tools()
+    for p in (ORACLE_SO, ORACLE_EXE, EMUL_SO, SYNTH_EXE):
+        assert os.path.exists(p), p
+    _built_once = True
 
 
 class _OP(C.Structure):

@@ -1,7 +1,7 @@
 """First-light script for a GPU box: streams synthetic sets through the C ABI and compares with the oracle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import util
 import microcket_amd as m
 
