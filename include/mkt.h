@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 4
+#define MKT_ABI_VERSION 5
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -53,7 +53,7 @@ typedef struct mkt_params {
     int32_t write_sam;         /* 0: argv[7] starts with N/n/0                 sam2pairs.cpp:47 */
     int32_t ref_threads;       /* argv[4] (>= 2): only the logged selfCircle depends on it (quirk Q2) */
     int32_t device;            /* HIP device ordinal */
-    uint64_t block_bytes;      /* bytes of SAM text per kernel pass, 0 = default (256 MiB); < 2 GiB - 64 KiB */
+    uint64_t block_bytes;      /* streaming path: bytes of SAM text per kernel pass, 0 = default (64 MiB); < 2 GiB - 64 KiB */
     int32_t tiles;             /* MKT_TILES_* */
     int32_t ordered;           /* 1: outputs in input order (deterministic bytes); 0 (default): any order, like the
                                 * reference, whose worker threads fwrite concurrently (sam2pairs.cpp:154,175) */
@@ -105,11 +105,24 @@ void mkt_destroy(mkt_ctx* ctx);
 
 /* ---- streaming path: host bytes in, host bytes out (what the sam2pairs executable uses) -------
  * mkt_submit takes the next bytes of the SAM stream in any chunking; `last` != 0 ends the input.
- * Complete QNAME groups are processed on the GPU as soon as a block fills; mkt_drain hands back
- * the output bytes that are final (everything except the newest group, see quirk Q1).  The
- * pointers stay valid until the next call on the context. */
+ * The path is a pipeline: a full block (block_bytes, cut on a QNAME-group boundary) is queued on the GPU -- H2D copy,
+ * kernels, output gather -- and the call returns; a worker thread inside the library takes the results in input order,
+ * copies the outputs back and publishes what is final (everything except the newest group, see quirk Q1).  Reading the
+ * next block, the PCIe copies in both directions, the kernels and the consumer's writes all overlap.  A kernel-side
+ * problem (e.g. an output buffer guess that was too small, a line table overflow) is repaired by re-running the affected
+ * blocks; what cannot be repaired is reported by the next call on the context (mkt_last_error has the text).
+ *
+ * mkt_drain (non-blocking) hands back, as one contiguous copy, every output byte published so far; the pointers stay
+ * valid until the next drain call.  mkt_finish waits for the pipeline, so submit .. finish .. drain from ONE thread
+ * always sees everything.
+ * mkt_drain_wait is the zero-copy form for a dedicated consumer thread (the executable's writer): it blocks until a
+ * chunk of output is published and hands out pointers into the pinned staging buffer it was copied to (valid until the
+ * next mkt_drain_wait call, which gives the buffer back: a slow consumer throttles the pipeline); *done = 1 with empty
+ * ranges once mkt_finish has run and everything was handed out.  One thread may call mkt_drain_wait while another one
+ * feeds the context; no other concurrent use of a context is allowed. */
 int mkt_submit(mkt_ctx* ctx, const char* bytes, size_t n, int last);
 int mkt_drain(mkt_ctx* ctx, mkt_out* out);
+int mkt_drain_wait(mkt_ctx* ctx, mkt_out* out, int* done);
 /* The same without the intermediate copy: mkt_input_window hands out the free part of the context's pinned input block
  * (*cap > 0 bytes at *buf; a full block is processed first); the caller reads the next bytes of the SAM stream straight
  * into it (read / pread, several threads if it likes) and commits them with mkt_submit_window.  Do not mix with

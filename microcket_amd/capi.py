@@ -10,7 +10,7 @@ EXT_KEYS = 1
 EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
     "mkt_input_window", "mkt_submit_window",
-    "mkt_submit", "mkt_drain", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
+    "mkt_submit", "mkt_drain", "mkt_drain_wait", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
 ]
@@ -73,6 +73,7 @@ def load_library():
     L.mkt_destroy.restype = None
     L.mkt_submit.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int]
     L.mkt_drain.argtypes = [C.c_void_p, C.POINTER(Out)]
+    L.mkt_drain_wait.argtypes = [C.c_void_p, C.POINTER(Out), C.POINTER(C.c_int)]
     L.mkt_input_window.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.mkt_submit_window.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
     L.mkt_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

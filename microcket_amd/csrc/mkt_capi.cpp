@@ -10,6 +10,10 @@
 #include <string>
 #include <utility>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/mkt.h"
@@ -50,11 +54,34 @@ struct mkt_ctx {
     uint8_t* d_ws = nullptr; size_t ws_cap = 0;
     DevRun* d_run = nullptr;
     // host (pinned)
-    uint8_t* h_in = nullptr; size_t h_len = 0;
+    size_t h_len = 0;                   // bytes in the input slot being filled
     BlockResult* h_res = nullptr; size_t res_slots = 0, res_used = 0, res_folded = 0;
-    uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;   // pinned D2H landing for block outputs (pageable copies pin/unpin per call)
-    // streaming outputs
-    std::vector<char> out_pairs, out_sam, tail_pairs, tail_sam, drained_pairs, drained_sam;
+    // ---- streaming pipeline (mkt_submit / mkt_input_window): the caller fills pinned input slots and queues GPU work
+    // without waiting; one worker thread takes the results in order, copies the outputs back and hands them to the
+    // consumer (mkt_drain / mkt_drain_wait).  reader || H2D || kernels || D2H || writer all overlap.
+    static constexpr int kIn = 3, kOut = 2;
+    static constexpr size_t kHead = 65536;                // room in front of a staged output for the held-back group of the block before
+    struct InSlot { uint8_t* h = nullptr; uint8_t* d = nullptr; bool busy = false; hipEvent_t h2d = nullptr, k0 = nullptr, k1 = nullptr, done = nullptr; };
+    struct OutSlot { uint8_t* d_pairs = nullptr; size_t d_pairs_cap = 0; uint8_t* d_sam = nullptr; size_t d_sam_cap = 0;
+                     uint8_t* h = nullptr; size_t h_cap = 0; bool dev_busy = false, host_busy = false; };
+    struct Job { int in_slot, out_slot; size_t n; int cfg; int attempts; };
+    struct Chunk { const char* pairs = nullptr; size_t pairs_len = 0; const char* sam = nullptr; size_t sam_len = 0; int out_slot = -1;
+                   std::vector<char> own_pairs, own_sam; };
+    InSlot in[kIn];
+    OutSlot outs[kOut];
+    std::deque<Job> jobs;                                 // queued on the GPU, results not yet taken (front = oldest)
+    std::deque<Chunk> ready;                              // final output bytes waiting for the consumer
+    Chunk handed; bool handed_valid = false;              // what mkt_drain_wait returned last (its staging slot is released by the next call)
+    std::mutex mu;
+    std::condition_variable cv;
+    std::thread worker;
+    bool worker_started = false, stop = false;
+    int async_rc = MKT_OK;                                // first error the worker met; every later call reports it
+    bool consumer_async = false;                          // mkt_drain_wait in use: another thread takes the outputs, so a full staging slot means WAIT (back-pressure)
+    int cur = 0;                                          // input slot the caller is filling
+    uint64_t seq = 0;
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    std::vector<char> tail_pairs, tail_sam, drained_pairs, drained_sam;
     RunAccum acc;
     bool input_done = false, finished = false;
     uint64_t bytes_in = 0, blocks = 0;
@@ -125,10 +152,18 @@ static size_t ws_tiles_bytes(uint32_t ntiles) {
 // fixed part: region cursors | 256 B of counters | up to 1024 scan words (one per 1024 tiles)
 static size_t ws_fixed_bytes() { return kMaxRegions * sizeof(RegionCur) + 256 + 1024 * sizeof(uint64_t); }
 static size_t ws_bytes_for(uint32_t ntiles) { return ws_tiles_bytes(ntiles) + ws_fixed_bytes() + sizeof(BlockResult); }
+// every stream of the context idle (before a device buffer that queued work may still use is freed)
+static int sync_all(mkt_ctx* c) {
+    if (c->s_in) HIPCHK(c, hipStreamSynchronize(c->s_in));
+    if (c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->s_out) HIPCHK(c, hipStreamSynchronize(c->s_out));
+    return MKT_OK;
+}
 static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
     size_t need = ws_bytes_for(ntiles);
     if (need <= c->ws_cap) return MKT_OK;
-    if (c->d_ws) HIPCHK(c, hipFree(c->d_ws));
+    need += need / 4;
+    if (c->d_ws) { int rc = sync_all(c); if (rc) return rc; HIPCHK(c, hipFree(c->d_ws)); }
     c->d_ws = nullptr; c->ws_cap = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_ws, need));
     c->ws_cap = need;
@@ -136,7 +171,7 @@ static int ensure_ws(mkt_ctx* c, uint32_t ntiles) {
 }
 static int ensure_dev(mkt_ctx* c, uint8_t** p, size_t* cap, size_t need) {
     if (need <= *cap) return MKT_OK;
-    if (*p) HIPCHK(c, hipFree(*p));
+    if (*p) { int rc = sync_all(c); if (rc) return rc; HIPCHK(c, hipFree(*p)); }
     *p = nullptr; *cap = 0;
     need += need / 8 + 4096;
     HIPCHK(c, hipMalloc((void**)p, need));
@@ -157,7 +192,7 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
     c->P.mode = p->mode; c->P.ratio = p->min_mapped_ratio; c->P.min_mapq = (uint32_t)p->min_mapq; c->P.write_sam = p->write_sam ? 1 : 0;
     c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;
     { const char* e = getenv("MKT_NO_LEAN"); c->no_lean = e && e[0] == '1'; }
-    size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)256 << 20);
+    size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)64 << 20);
     if (bc < 4096) bc = 4096;
     if (bc >= kMaxBlock) bc = kMaxBlock - 4096;
     bc = (bc + 15) & ~(size_t)15;
@@ -178,7 +213,26 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
 void mkt_destroy(mkt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->p.device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->worker_started) {
+        { std::lock_guard<std::mutex> g(c->mu); c->stop = true; }
+        c->cv.notify_all();
+        c->worker.join();
+    }
+    (void)sync_all(c);
+    for (int i = 0; i < mkt_ctx::kIn; ++i) {
+        mkt_ctx::InSlot& s = c->in[i];
+        if (s.h) (void)hipHostFree(s.h);
+        if (s.d) (void)hipFree(s.d);
+        if (s.h2d) { (void)hipEventDestroy(s.h2d); (void)hipEventDestroy(s.k0); (void)hipEventDestroy(s.k1); (void)hipEventDestroy(s.done); }
+    }
+    for (int i = 0; i < mkt_ctx::kOut; ++i) {
+        mkt_ctx::OutSlot& o = c->outs[i];
+        if (o.d_pairs) (void)hipFree(o.d_pairs);
+        if (o.d_sam) (void)hipFree(o.d_sam);
+        if (o.h) (void)hipHostFree(o.h);
+    }
+    if (c->s_in) (void)hipStreamDestroy(c->s_in);
+    if (c->s_out) (void)hipStreamDestroy(c->s_out);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
@@ -192,9 +246,7 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_run) (void)hipFree(c->d_run);
     if (c->d_syn) (void)hipFree(c->d_syn);
     if (c->d_syn_sizes) (void)hipFree(c->d_syn_sizes);
-    if (c->h_in) (void)hipHostFree(c->h_in);
     if (c->h_res) (void)hipHostFree(c->h_res);
-    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_sc_logged) (void)hipFree(c->d_sc_logged);
     if (c->h_chr_stage) (void)hipHostFree(c->h_chr_stage);
     if (c->d_dd_flags) (void)hipFree(c->d_dd_flags);
@@ -221,8 +273,11 @@ static bool adapt_geometry(mkt_ctx* c, const BlockResult& r) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// enqueue one block: memset workspace, tile kernel (timed), finish kernel, result D2H into slot
-static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, size_t slot) {
+// enqueue one block: memset workspace, tile kernel (timed), finish kernel, result D2H into slot.
+// so (streaming path): the block's outputs are also gathered into the contiguous buffers of an output slot, the timing
+// events are the input slot's own, and `done` is recorded behind everything.
+struct StreamOut { uint8_t* gp; size_t gp_cap; uint8_t* gs; size_t gs_cap; hipEvent_t k0, k1, done; };
+static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, size_t slot, const StreamOut* so = nullptr) {
     if (((uintptr_t)d_text & 15u) != 0) return fail(c, MKT_E_ARG, "block text must be 16-byte aligned");
     if (n >= kMaxBlock) return fail(c, MKT_E_ARG, "block of %zu bytes: must be < 2 GiB - 64 KiB", n);
     const uint32_t ntiles = num_tiles((uint32_t)n, tile_bytes(cfg));
@@ -261,7 +316,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     {
         const size_t need = (size_t)a.nregions * ((n / 256 / (size_t)a.nregions) * 2 + 1024);
         if (c->sc_tmp_cap < need) {
-            if (c->d_sc_tmp) HIPCHK(c, hipFree(c->d_sc_tmp));
+            if (c->d_sc_tmp) { if ((rc = sync_all(c))) return rc; HIPCHK(c, hipFree(c->d_sc_tmp)); }
             c->d_sc_tmp = nullptr; c->sc_tmp_cap = 0;
             HIPCHK(c, hipMalloc((void**)&c->d_sc_tmp, need * sizeof(uint64_t)));
             c->sc_tmp_cap = need;
@@ -279,7 +334,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
         // at most one reported pair per two 32-byte lines; twice that per region for imbalance
         const size_t per = (n / 64 / (size_t)a.nregions) * 2 + 4096, need = per * a.nregions;
         if (c->keys_raw_cap < need) {
-            if (c->d_keys_raw) HIPCHK(c, hipFree(c->d_keys_raw));
+            if (c->d_keys_raw) { if ((rc = sync_all(c))) return rc; HIPCHK(c, hipFree(c->d_keys_raw)); }
             c->d_keys_raw = nullptr; c->keys_raw_cap = 0;
             HIPCHK(c, hipMalloc((void**)&c->d_keys_raw, need * sizeof(KeyRec)));
             c->keys_raw_cap = need;
@@ -309,9 +364,12 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
 #endif
     HIPCHK(c, hipMemsetAsync(c->d_ws, 0, ws_bytes_for(ntiles), c->stream));
     hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0));
-    HIPCHK(c, hipEventCreate(&e1));
-    c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
+    if (so) { e0 = so->k0; e1 = so->k1; }
+    else {
+        HIPCHK(c, hipEventCreate(&e0));
+        HIPCHK(c, hipEventCreate(&e1));
+        c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
+    }
     int grid = (int)(ntiles < 1024u ? ntiles : 1024u);
     const bool lean = !c->p.ordered && cfg != CFG_SMALL && !c->no_lean;
     HIPCHK(c, hipEventRecord(e0, c->stream));
@@ -327,7 +385,13 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
         HIPCHK(c, hipEventRecord(e1, c->stream));
     }
     HIPCHK(c, launch_finish(a, c->stream));
+    if (so) {
+        const uint64_t prc = a.nregions > 1 ? a.pairs_rcap : 0, src_ = a.nregions > 1 ? a.sam_rcap : 0;
+        HIPCHK(c, launch_gather(a.res, c->d_pairs, prc, so->gp, so->gp_cap, 0, n / 8, c->stream));
+        if (c->P.write_sam) HIPCHK(c, launch_gather(a.res, c->d_sam, src_, so->gs, so->gs_cap, 1, n, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(&c->h_res[slot], a.res, sizeof(BlockResult), hipMemcpyDeviceToHost, c->stream));
+    if (so) HIPCHK(c, hipEventRecord(so->done, c->stream));
     return MKT_OK;
 }
 
@@ -384,127 +448,309 @@ static int check_result(mkt_ctx* c, const BlockResult& r) {
                 (r.err & E_SC_CAP) ? " [self-circle buffer]" : "", (r.err & E_FIELD_RANGE) ? " [field > 65535 bytes]" : "");
 }
 
-// run one host block synchronously, with the automatic retries (small tiles / bigger buffers)
-static int run_host_block(mkt_ctx* c, size_t n) {
+// ---------------------------------------------------------------------------------------------
+// Streaming path.  Caller thread: fills input slot `cur`, cuts it on a group boundary, queues H2D + kernels + gather for
+// the prefix and moves on to the next slot with the carry.  Worker thread: per job, in order -- wait for the result, fold
+// it into the run, copy the gathered outputs into a pinned staging slot, hold back the block's last group (quirk Q1),
+// publish the rest.  Everything shared is guarded by c->mu; blocking waits on the GPU happen outside it.
+
+static int stream_start(mkt_ctx* c) {
+    if (!c->s_in) HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+    if (!c->s_out) HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+    return MKT_OK;
+}
+static int stream_alloc_in(mkt_ctx* c, int i) {
+    mkt_ctx::InSlot& s = c->in[i];
+    if (!s.h) HIPCHK(c, hipHostMalloc((void**)&s.h, c->block_cap + 64, hipHostMallocDefault));
+    return MKT_OK;
+}
+static int stream_alloc_dev(mkt_ctx* c, int i) {
+    mkt_ctx::InSlot& s = c->in[i];
+    if (!s.d) HIPCHK(c, hipMalloc((void**)&s.d, c->block_cap + 64));
+    if (!s.h2d) {
+        HIPCHK(c, hipEventCreateWithFlags(&s.h2d, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreate(&s.k0));
+        HIPCHK(c, hipEventCreate(&s.k1));
+        HIPCHK(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    return MKT_OK;
+}
+static void worker_main(mkt_ctx* c);
+
+// queue the GPU work of one job (c->mu held; the job's input is in d_in already or on its way on s_in)
+static int stream_launch(mkt_ctx* c, const mkt_ctx::Job& j) {
+    mkt_ctx::InSlot& is = c->in[j.in_slot];
+    mkt_ctx::OutSlot& os = c->outs[j.out_slot];
     int rc;
-    if (!c->d_in) { HIPCHK(c, hipMalloc((void**)&c->d_in, c->block_cap + 64)); }
-    HIPCHK(c, hipMemcpyAsync(c->d_in, c->h_in, n, hipMemcpyHostToDevice, c->stream));
-    int cfg = c->cfg;
-    BlockResult r;
-    if ((rc = ensure_sc_list(c, (size_t)c->acc.sc + n / 64 + 4096))) return rc;      // at most one group per 64 input bytes
-    for (int attempt = 0;; ++attempt) {
-        if ((rc = enqueue_block(c, c->d_in, n, cfg, 0))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        fold_timing(c);
-        r = c->h_res[0];
-        if (r.err == 0) break;
-        if (attempt >= 3) return check_result(c, r);
-        if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && cfg != CFG_SMALL && c->p.tiles == MKT_TILES_AUTO) { cfg = cfg == CFG_FAST ? CFG_MID : (cfg == CFG_MID ? CFG_DENSE : CFG_SMALL); continue; }
-        bool grew = false;
+    // the region buffers are sized here once for a whole block (never regrown in flight except by a replay, which is idle)
+    if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, c->block_cap / 3 + 65536))) return rc;
+    if (c->P.write_sam && (rc = ensure_dev(c, &c->d_sam, &c->sam_cap, c->block_cap + c->block_cap / 4 + 65536))) return rc;
+    if (os.d_pairs_cap < c->pairs_cap) { if ((rc = ensure_dev(c, &os.d_pairs, &os.d_pairs_cap, c->pairs_cap))) return rc; }
+    if (c->P.write_sam && os.d_sam_cap < c->sam_cap) { if ((rc = ensure_dev(c, &os.d_sam, &os.d_sam_cap, c->sam_cap))) return rc; }
+    StreamOut so;
+    so.gp = os.d_pairs; so.gp_cap = os.d_pairs_cap; so.gs = os.d_sam; so.gs_cap = os.d_sam_cap;
+    so.k0 = is.k0; so.k1 = is.k1; so.done = is.done;
+    return enqueue_block(c, is.d, j.n, j.cfg, c->res_slots - mkt_ctx::kIn + (size_t)j.in_slot, &so);
+}
+
+// c->mu held by lk.  Hands input slot `slot` (n bytes) to the GPU.
+static int stream_enqueue(mkt_ctx* c, std::unique_lock<std::mutex>& lk, int slot, size_t n) {
+    int rc;
+    if ((rc = stream_start(c))) return rc;
+    const int oslot = (int)(c->seq % mkt_ctx::kOut);
+    // the output slot's device buffers are free once the job two back has been copied out
+    c->cv.wait(lk, [&] { return c->async_rc != MKT_OK || !c->outs[oslot].dev_busy; });
+    if (c->async_rc) return c->async_rc;
+    // room in the run's self-circle list for every block in flight at one group per 64 input bytes; growing it needs the
+    // pipeline idle (only the entries of folded blocks are carried over)
+    const size_t per_block = c->block_cap / 64 + 4096;
+    if (!c->d_sc || (size_t)c->acc.sc + (c->jobs.size() + 1) * per_block > c->sc_cap) {
+        c->cv.wait(lk, [&] { return c->async_rc != MKT_OK || c->jobs.empty(); });
+        if (c->async_rc) return c->async_rc;
+        if ((rc = ensure_sc_list(c, 2 * (size_t)c->acc.sc + (size_t)(mkt_ctx::kOut + 1) * per_block))) return rc;
+    }
+    if ((rc = stream_alloc_dev(c, slot))) return rc;
+    mkt_ctx::InSlot& is = c->in[slot];
+    HIPCHK(c, hipMemcpyAsync(is.d, is.h, n, hipMemcpyHostToDevice, c->s_in));
+    HIPCHK(c, hipEventRecord(is.h2d, c->s_in));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, is.h2d, 0));
+    mkt_ctx::Job j;
+    j.in_slot = slot; j.out_slot = oslot; j.n = n; j.cfg = c->cfg; j.attempts = 0;
+    c->bytes_unsynced = 0;
+    for (const mkt_ctx::Job& q : c->jobs) c->bytes_unsynced += q.n;     // extension: key-list reservation covers the blocks in flight
+    if ((rc = stream_launch(c, j))) return rc;
+    is.busy = true; c->outs[oslot].dev_busy = true;
+    c->jobs.push_back(j);
+    ++c->seq;
+    if (!c->worker_started) { c->worker_started = true; c->worker = std::thread(worker_main, c); }
+    c->cv.notify_all();
+    return MKT_OK;
+}
+
+// A job came back with error bits (c->mu held, worker thread): fix the cause the way a synchronous run would -- next
+// smaller tile geometry, bigger output buffers -- and run it again, followed by every job queued behind it (they ran on
+// top of run totals that the failed block never advanced).  Inputs are still in their device slots.
+static int stream_replay(mkt_ctx* c, const BlockResult& r) {
+    int rc;
+    if ((rc = sync_all(c))) return rc;
+    mkt_ctx::Job& j0 = c->jobs.front();
+    if (++j0.attempts > 4) return check_result(c, r);
+    bool fixed = false;
+    if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && j0.cfg != CFG_SMALL && c->p.tiles == MKT_TILES_AUTO) {
+        const int ncfg = j0.cfg == CFG_FAST ? CFG_MID : (j0.cfg == CFG_MID ? CFG_DENSE : CFG_SMALL);
+        for (mkt_ctx::Job& q : c->jobs) q.cfg = ncfg;
+        if (ncfg != CFG_SMALL) c->cfg = ncfg;              // the stream keeps the geometry that fits its lines (the 256-byte tiles are a last resort per block)
+        fixed = true;
+    } else {
         const uint32_t nr = r.nregions ? r.nregions : 1;
         if (r.err & E_PAIRS_CAP) {
             uint64_t mx = 0; for (uint32_t q = 0; q < nr; ++q) if (r.rpair[q] > mx) mx = r.rpair[q];
-            if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc; grew = true;
+            if ((rc = ensure_dev(c, &c->d_pairs, &c->pairs_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc;
+            fixed = true;
         }
         if (r.err & E_SAM_CAP) {
             uint64_t mx = 0; for (uint32_t q = 0; q < nr; ++q) if (r.rsam[q] > mx) mx = r.rsam[q];
-            if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc; grew = true;
+            if ((rc = ensure_dev(c, &c->d_sam, &c->sam_cap, (size_t)(mx * nr) + mx / 4 * nr + 65536))) return rc;
+            fixed = true;
         }
         if (r.err & E_SC_CAP) {            // per-block raw entries: grow the slices, and the run's list with them
-            size_t need = (size_t)r.sc * 4 + 65536;
+            const size_t need = (size_t)r.sc * 4 + 65536;
             if (c->d_sc_tmp) HIPCHK(c, hipFree(c->d_sc_tmp));
             c->d_sc_tmp = nullptr; c->sc_tmp_cap = 0;
             HIPCHK(c, hipMalloc((void**)&c->d_sc_tmp, need * kMaxRegions * sizeof(uint64_t)));
             c->sc_tmp_cap = need * kMaxRegions;
-            if ((rc = ensure_sc_list(c, (size_t)c->acc.sc + need))) return rc;
-            c->key_density = 0;                // extension: the key list may be what overflowed: back to the worst-case reservation
-            grew = true;
+            if ((rc = ensure_sc_list(c, (size_t)c->acc.sc + (c->jobs.size() + 1) * need))) return rc;
+            c->key_density = 0;            // extension: the key list may be what overflowed: back to the worst-case reservation
+            fixed = true;
         }
-        if (!grew) return check_result(c, r);
     }
-    // fetch outputs
-    c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad; adapt_geometry(c, r);
-    ++c->blocks;
-    c->sc_unfolded += r.sc; c->emitted_unfolded += r.emitted; c->bytes_unsynced += n;
-    note_sc_density(c);
-    size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
-    if (c->h_stage_cap < pb + sb) {
-        if (c->h_stage) HIPCHK(c, hipHostFree(c->h_stage));
-        c->h_stage = nullptr; c->h_stage_cap = 0;
-        const size_t want = (pb + sb) + (pb + sb) / 4 + 65536;
-        HIPCHK(c, hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault));
-        c->h_stage_cap = want;
-    }
-    // gather the region slices: .pairs regions first, then .sam regions; remember where each region landed
-    const uint32_t nreg = r.nregions ? r.nregions : 1;
-    const size_t prc = (c->pairs_cap / nreg) & ~(size_t)15, src_ = c->P.write_sam ? ((c->sam_cap / nreg) & ~(size_t)15) : 0;
-    size_t pstart[kMaxRegions], sstart[kMaxRegions], acc_p = 0, acc_s = pb;
-    for (uint32_t q = 0; q < nreg; ++q) {
-        pstart[q] = acc_p; sstart[q] = acc_s;
-        if (r.rpair[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage + acc_p, c->d_pairs + (size_t)q * prc, (size_t)r.rpair[q], hipMemcpyDeviceToHost, c->stream));
-        if (sb && r.rsam[q]) HIPCHK(c, hipMemcpyAsync(c->h_stage + acc_s, c->d_sam + (size_t)q * src_, (size_t)r.rsam[q], hipMemcpyDeviceToHost, c->stream));
-        acc_p += (size_t)r.rpair[q]; acc_s += sb ? (size_t)r.rsam[q] : 0;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const char* hp = (const char*)c->h_stage;
-    if (r.last.valid) {
-        // the previous newest group is now final: release its bytes; hold back the new newest group's
-        // (its bytes sit at [pair_off, +pair_bytes) / [sam_off, +sam_bytes) of this block's outputs)
-        c->out_pairs.insert(c->out_pairs.end(), c->tail_pairs.begin(), c->tail_pairs.end());
-        c->out_sam.insert(c->out_sam.end(), c->tail_sam.begin(), c->tail_sam.end());
-        const uint32_t lr = r.last.region < nreg ? r.last.region : 0;
-        const size_t tp = r.last.pair_bytes, po = pstart[lr] + r.last.pair_off;
-        const size_t ts = c->P.write_sam ? r.last.sam_bytes : 0, so = sb ? (sstart[lr] - pb) + r.last.sam_off : 0;
-        c->out_pairs.insert(c->out_pairs.end(), hp, hp + po);
-        c->out_pairs.insert(c->out_pairs.end(), hp + po + tp, hp + pb);
-        c->tail_pairs.assign(hp + po, hp + po + tp);
-        if (sb) {
-            c->out_sam.insert(c->out_sam.end(), hp + pb, hp + pb + so);
-            c->out_sam.insert(c->out_sam.end(), hp + pb + so + ts, hp + pb + sb);
-            c->tail_sam.assign(hp + pb + so, hp + pb + so + ts);
-        } else c->tail_sam.clear();
+    if (!fixed) return check_result(c, r);
+    // the run totals on the device go back to what the folded blocks left
+    DevRun dr;
+    dr.groups = c->acc.groups; dr.sc = c->acc.sc; dr.emitted = c->acc.emitted;
+    HIPCHK(c, hipMemcpy(c->d_run, &dr, sizeof dr, hipMemcpyHostToDevice));
+    c->bytes_unsynced = 0;
+    for (const mkt_ctx::Job& q : c->jobs) {
+        if ((rc = stream_launch(c, q))) return rc;
+        c->bytes_unsynced += q.n;
     }
     return MKT_OK;
 }
 
-// the input block is full (or the input ended): run its group-aligned prefix, keep the rest
-static int flush_block(mkt_ctx* c, bool everything) {
+static void worker_fail(mkt_ctx* c, int rc) {       // c->mu held
+    if (c->async_rc == MKT_OK) c->async_rc = rc ? rc : MKT_E_HIP;
+    c->cv.notify_all();
+}
+
+static void worker_main(mkt_ctx* c) {
+    (void)hipSetDevice(c->p.device);
+    std::unique_lock<std::mutex> lk(c->mu);
+    for (;;) {
+        c->cv.wait(lk, [&] { return c->stop || (!c->jobs.empty() && c->async_rc == MKT_OK); });
+        if (c->stop) return;
+        const mkt_ctx::Job j = c->jobs.front();
+        hipEvent_t done = c->in[j.in_slot].done;
+        lk.unlock();
+        hipError_t he = hipEventSynchronize(done);
+        lk.lock();
+        if (c->stop) return;
+        if (he != hipSuccess) { fail(c, MKT_E_HIP, "hipEventSynchronize failed: %s", hipGetErrorString(he)); worker_fail(c, MKT_E_HIP); continue; }
+        const BlockResult r = c->h_res[c->res_slots - mkt_ctx::kIn + (size_t)j.in_slot];
+        if (r.err) {
+            const int rc = stream_replay(c, r);
+            if (rc) worker_fail(c, rc);
+            continue;                                  // wait for the re-run of the same job
+        }
+        // ---- fold the block into the run
+        c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad; adapt_geometry(c, r);
+        ++c->blocks;
+        c->sc_unfolded += r.sc; c->emitted_unfolded += r.emitted; c->bytes_unsynced = j.n;
+        note_sc_density(c);
+        {
+            float ms = 0;
+            mkt_ctx::InSlot& is = c->in[j.in_slot];
+            if (hipEventElapsedTime(&ms, is.k0, is.k1) == hipSuccess) { c->folded_ms += ms; ++c->folded_launches; c->folded_bytes += j.n; }
+        }
+        const size_t pb = (size_t)r.pair_bytes, sb = c->P.write_sam ? (size_t)r.sam_bytes : 0;
+        mkt_ctx::OutSlot& os = c->outs[j.out_slot];
+        // ---- copy the gathered outputs out (the staging slot must be back from the consumer)
+        while (os.host_busy && !c->stop) {
+            if (!c->consumer_async) {
+                // single-threaded caller (submit ... drain later): nobody will release the slot while the caller is inside
+                // mkt_submit, so its published chunk moves to the heap instead
+                for (mkt_ctx::Chunk& q : c->ready)
+                    if (q.out_slot == j.out_slot) {
+                        q.own_pairs.assign(q.pairs, q.pairs + q.pairs_len); q.own_sam.assign(q.sam, q.sam + q.sam_len);
+                        q.pairs = q.own_pairs.data(); q.sam = q.own_sam.data(); q.out_slot = -1;
+                    }
+                if (!(c->handed_valid && c->handed.out_slot == j.out_slot)) { os.host_busy = false; break; }
+            }
+            c->cv.wait(lk);
+        }
+        if (c->stop) return;
+        const size_t H = mkt_ctx::kHead;
+        const size_t sam_at = ((H + pb + 4095) & ~(size_t)4095) + H, need = sam_at + sb + 64;
+        bool bad = false;
+        if (pb + sb) {
+            if (os.h_cap < need) {
+                if (os.h) (void)hipHostFree(os.h);
+                os.h = nullptr; os.h_cap = 0;
+                const size_t want = need + need / 4;
+                if (hipHostMalloc((void**)&os.h, want, hipHostMallocDefault) != hipSuccess) { fail(c, MKT_E_NOMEM, "pinned staging of %zu bytes", want); worker_fail(c, MKT_E_NOMEM); bad = true; }
+                else os.h_cap = want;
+            }
+            if (!bad) {
+                lk.unlock();
+                hipError_t e1 = pb ? hipMemcpyAsync(os.h + H, os.d_pairs, pb, hipMemcpyDeviceToHost, c->s_out) : hipSuccess;
+                hipError_t e2 = sb ? hipMemcpyAsync(os.h + sam_at, os.d_sam, sb, hipMemcpyDeviceToHost, c->s_out) : hipSuccess;
+                hipError_t e3 = hipStreamSynchronize(c->s_out);
+                lk.lock();
+                if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { fail(c, MKT_E_HIP, "output copy failed"); worker_fail(c, MKT_E_HIP); bad = true; }
+            }
+        }
+        if (c->stop) return;
+        if (bad) continue;
+        // ---- quirk Q1: the newest group stays back until a later group supersedes it
+        mkt_ctx::Chunk ch;
+        ch.out_slot = j.out_slot;
+        const char* hp = (const char*)os.h + H;
+        const char* hs = (const char*)os.h + sam_at;
+        if (r.last.valid) {
+            const size_t tp = r.last.pair_bytes, ts = c->P.write_sam ? r.last.sam_bytes : 0;      // gathered layout: [ the rest | last group ]
+            const size_t bp = pb - tp, bs = sb - ts;
+            ch.pairs = hp; ch.pairs_len = bp; ch.sam = hs; ch.sam_len = bs;
+            if (!c->tail_pairs.empty() || !c->tail_sam.empty()) {
+                if (pb + sb && c->tail_pairs.size() <= H && c->tail_sam.size() <= H) {             // in front of this block's bytes
+                    if (!c->tail_pairs.empty()) { memcpy(os.h + H - c->tail_pairs.size(), c->tail_pairs.data(), c->tail_pairs.size()); ch.pairs = hp - c->tail_pairs.size(); ch.pairs_len += c->tail_pairs.size(); }
+                    if (!c->tail_sam.empty()) { memcpy(os.h + sam_at - c->tail_sam.size(), c->tail_sam.data(), c->tail_sam.size()); ch.sam = hs - c->tail_sam.size(); ch.sam_len += c->tail_sam.size(); }
+                } else {                                                                           // as a chunk of its own
+                    mkt_ctx::Chunk t;
+                    t.own_pairs.swap(c->tail_pairs); t.own_sam.swap(c->tail_sam);
+                    c->ready.push_back(std::move(t));
+                }
+            }
+            if (tp) c->tail_pairs.assign(hp + bp, hp + bp + tp); else c->tail_pairs.clear();
+            if (ts) c->tail_sam.assign(hs + bs, hs + bs + ts); else c->tail_sam.clear();
+        } else {
+            ch.pairs = hp; ch.pairs_len = pb; ch.sam = hs; ch.sam_len = sb;                        // a block without any group reports nothing
+        }
+        if (ch.pairs_len + ch.sam_len) { os.host_busy = true; c->ready.push_back(std::move(ch)); }
+        os.dev_busy = false;
+        c->in[j.in_slot].busy = false;
+        c->jobs.pop_front();
+        c->cv.notify_all();
+    }
+}
+
+// c->mu held by lk: every queued job folded (or an error)
+static int stream_wait_idle(mkt_ctx* c, std::unique_lock<std::mutex>& lk) {
+    c->cv.wait(lk, [&] { return c->async_rc != MKT_OK || c->jobs.empty(); });
+    return c->async_rc;
+}
+
+// the input slot is full (or the input ended): queue its group-aligned prefix, carry the rest into the next slot
+static int stream_flush(mkt_ctx* c, bool everything) {
+    std::unique_lock<std::mutex> lk(c->mu);
+    if (c->async_rc) return c->async_rc;
+    mkt_ctx::InSlot& is = c->in[c->cur];
     if (everything) {
-        if (c->h_len) { int rc = run_host_block(c, c->h_len); if (rc) return rc; c->h_len = 0; }
+        if (c->h_len) { int rc = stream_enqueue(c, lk, c->cur, c->h_len); if (rc) return rc; }
+        c->cur = (c->cur + 1) % mkt_ctx::kIn;
+        c->h_len = 0;
         return MKT_OK;
     }
-    const size_t cut = group_aligned_prefix((const char*)c->h_in, c->h_len, c->P.min_mapq);
-    if (cut == 0) return fail(c, MKT_E_CAPACITY, "no QNAME-group boundary inside a %zu-byte block: raise block_bytes", c->block_cap);
-    int rc = run_host_block(c, cut);
+    size_t end = 0;
+    const size_t cut = group_aligned_prefix((const char*)is.h, c->h_len, c->P.min_mapq, &end);
+    if (cut == 0) {
+        // one group (or none closed) in the whole slot: lines that the filter drops influence nothing, squeeze them out
+        const size_t nl = compact_carry((char*)is.h, c->h_len, c->P.min_mapq);
+        if (nl + 4096 > c->h_len || nl + 4096 > c->block_cap)
+            return fail(c, MKT_E_CAPACITY, "no QNAME-group boundary inside a %zu-byte block: raise block_bytes", c->block_cap);
+        c->h_len = nl;
+        return MKT_OK;
+    }
+    const int next = (c->cur + 1) % mkt_ctx::kIn;
+    c->cv.wait(lk, [&] { return c->async_rc != MKT_OK || !c->in[next].busy; });
+    if (c->async_rc) return c->async_rc;
+    int rc = stream_alloc_in(c, next);
     if (rc) return rc;
-    memmove(c->h_in, c->h_in + cut, c->h_len - cut);
-    c->h_len -= cut;
+    size_t carry = c->h_len - cut;
+    memcpy(c->in[next].h, is.h + cut, carry);
+    if (carry > c->block_cap / 2) carry = compact_carry((char*)c->in[next].h, carry, c->P.min_mapq);
+    if ((rc = stream_enqueue(c, lk, c->cur, cut))) return rc;
+    c->cur = next;
+    c->h_len = carry;
     return MKT_OK;
+}
+
+static int stream_check_open(mkt_ctx* c) {
+    if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "input after the end of input");
+    { std::lock_guard<std::mutex> g(c->mu); if (c->async_rc) return c->async_rc; }
+    HIPCHK(c, hipSetDevice(c->p.device));
+    return stream_alloc_in(c, c->cur);
 }
 
 int mkt_submit(mkt_ctx* c, const char* bytes, size_t n, int last) {
     if (!c) return MKT_E_ARG;
-    if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "submit after the end of input");
     if (n && !bytes) return fail(c, MKT_E_ARG, "null bytes");
-    HIPCHK(c, hipSetDevice(c->p.device));
-    if (!c->h_in) HIPCHK(c, hipHostMalloc((void**)&c->h_in, c->block_cap + 64, hipHostMallocDefault));
+    int rc = stream_check_open(c);
+    if (rc) return rc;
     size_t pos = 0;
     c->bytes_in += n;
     for (;;) {
         size_t space = c->block_cap - c->h_len;
         size_t take = n - pos < space ? n - pos : space;
-        if (take) { memcpy(c->h_in + c->h_len, bytes + pos, take); c->h_len += take; pos += take; }
+        if (take) { memcpy(c->in[c->cur].h + c->h_len, bytes + pos, take); c->h_len += take; pos += take; }
         const bool all_in = pos == n;
         if (c->h_len == c->block_cap && !(all_in && last)) {
-            int rc = flush_block(c, false);
-            if (rc) return rc;
+            if ((rc = stream_flush(c, false))) return rc;
+            if ((rc = stream_alloc_in(c, c->cur))) return rc;
             continue;
         }
         if (all_in) break;
     }
     if (last) {
-        int rc = flush_block(c, true);
-        if (rc) return rc;
+        if ((rc = stream_flush(c, true))) return rc;
         c->input_done = true;
     }
     return MKT_OK;
@@ -512,39 +758,83 @@ int mkt_submit(mkt_ctx* c, const char* bytes, size_t n, int last) {
 
 int mkt_input_window(mkt_ctx* c, char** buf, size_t* cap) {
     if (!c || !buf || !cap) return MKT_E_ARG;
-    if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "input window after the end of input");
-    HIPCHK(c, hipSetDevice(c->p.device));
-    if (!c->h_in) HIPCHK(c, hipHostMalloc((void**)&c->h_in, c->block_cap + 64, hipHostMallocDefault));
-    if (c->h_len == c->block_cap) { int rc = flush_block(c, false); if (rc) return rc; }
-    *buf = (char*)c->h_in + c->h_len;
+    int rc = stream_check_open(c);
+    if (rc) return rc;
+    if (c->h_len == c->block_cap) {
+        if ((rc = stream_flush(c, false))) return rc;
+        if ((rc = stream_alloc_in(c, c->cur))) return rc;
+    }
+    *buf = (char*)c->in[c->cur].h + c->h_len;
     *cap = c->block_cap - c->h_len;
     return MKT_OK;
 }
 int mkt_submit_window(mkt_ctx* c, size_t n, int last) {
     if (!c) return MKT_E_ARG;
     if (c->input_done || c->finished) return fail(c, MKT_E_STATE, "submit after the end of input");
-    if (!c->h_in || n > c->block_cap - c->h_len) return fail(c, MKT_E_ARG, "more bytes than the input window holds");
+    if (!c->in[c->cur].h || n > c->block_cap - c->h_len) return fail(c, MKT_E_ARG, "more bytes than the input window holds");
     HIPCHK(c, hipSetDevice(c->p.device));
     c->h_len += n;
     c->bytes_in += n;
+    int rc;
     if (last) {
-        int rc = flush_block(c, true);
-        if (rc) return rc;
+        if ((rc = stream_flush(c, true))) return rc;
         c->input_done = true;
     } else if (c->h_len == c->block_cap) {
-        int rc = flush_block(c, false);
-        if (rc) return rc;
+        if ((rc = stream_flush(c, false))) return rc;
     }
     return MKT_OK;
 }
 
+// the staging slot of the chunk handed out last goes back to the worker (c->mu held)
+static void release_handed(mkt_ctx* c) {
+    if (c->handed_valid) {
+        if (c->handed.out_slot >= 0) c->outs[c->handed.out_slot].host_busy = false;
+        c->handed = mkt_ctx::Chunk();
+        c->handed_valid = false;
+        c->cv.notify_all();
+    }
+}
+static void chunk_ptrs(mkt_ctx::Chunk& ch) {        // a heap chunk's pointers follow its vectors (they move with the chunk)
+    if (ch.out_slot < 0) { ch.pairs = ch.own_pairs.data(); ch.pairs_len = ch.own_pairs.size(); ch.sam = ch.own_sam.data(); ch.sam_len = ch.own_sam.size(); }
+}
+
 int mkt_drain(mkt_ctx* c, mkt_out* out) {
     if (!c || !out) return MKT_E_ARG;
-    c->drained_pairs.swap(c->out_pairs); c->out_pairs.clear();
-    c->drained_sam.swap(c->out_sam); c->out_sam.clear();
+    std::unique_lock<std::mutex> lk(c->mu);
+    release_handed(c);
+    c->drained_pairs.clear(); c->drained_sam.clear();
+    while (!c->ready.empty()) {
+        mkt_ctx::Chunk& ch = c->ready.front();
+        chunk_ptrs(ch);
+        c->drained_pairs.insert(c->drained_pairs.end(), ch.pairs, ch.pairs + ch.pairs_len);
+        c->drained_sam.insert(c->drained_sam.end(), ch.sam, ch.sam + ch.sam_len);
+        if (ch.out_slot >= 0) c->outs[ch.out_slot].host_busy = false;
+        c->ready.pop_front();
+    }
+    c->cv.notify_all();
     out->pairs = c->drained_pairs.data(); out->pairs_len = c->drained_pairs.size();
     out->sam = c->drained_sam.data(); out->sam_len = c->drained_sam.size();
-    return MKT_OK;
+    return c->async_rc;
+}
+
+int mkt_drain_wait(mkt_ctx* c, mkt_out* out, int* done) {
+    if (!c || !out || !done) return MKT_E_ARG;
+    std::unique_lock<std::mutex> lk(c->mu);
+    release_handed(c);
+    memset(out, 0, sizeof *out);
+    *done = 0;
+    c->consumer_async = true;
+    c->cv.wait(lk, [&] { return c->async_rc != MKT_OK || !c->ready.empty() || c->finished; });
+    if (!c->ready.empty()) {
+        c->handed = std::move(c->ready.front());
+        c->ready.pop_front();
+        c->handed_valid = true;
+        chunk_ptrs(c->handed);
+        out->pairs = c->handed.pairs; out->pairs_len = c->handed.pairs_len; out->sam = c->handed.sam; out->sam_len = c->handed.sam_len;
+        return MKT_OK;
+    }
+    *done = 1;
+    return c->async_rc;
 }
 
 int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
@@ -556,7 +846,7 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     // ... and the first block of an input is a probe: its result (self-circle density, tiles the lean kernel could not
     // take) is looked at before the second block is queued
     const bool probe = c->probing && c->res_used >= 1;
-    if (probe || c->res_used == c->res_slots || (size_t)c->acc.sc + sc_estimate(c, c->bytes_unsynced + n) > c->sc_cap) {
+    if (probe || c->res_used == c->res_slots - mkt_ctx::kIn || (size_t)c->acc.sc + sc_estimate(c, c->bytes_unsynced + n) > c->sc_cap) {
         if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "submit_device: sync before block (slots %zu/%zu, unsynced %.1f GB, density %.3g /B, list %llu of %zu)\n",
                                               c->res_used, c->res_slots, (double)c->bytes_unsynced / 1e9, c->sc_density, (unsigned long long)c->acc.sc, c->sc_cap);
         int rc = mkt_sync(c);
@@ -577,6 +867,7 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
 int mkt_sync(mkt_ctx* c) {
     if (!c) return MKT_E_ARG;
     HIPCHK(c, hipSetDevice(c->p.device));
+    { std::unique_lock<std::mutex> lk(c->mu); const int arc = stream_wait_idle(c, lk); if (arc) return arc; }
     const bool dbg = getenv("MKT_DEBUG_SYNC") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = dbg ? now() : 0;
@@ -660,14 +951,19 @@ int mkt_finish(mkt_ctx* c, int drop_last, uint64_t group_offset, uint64_t total_
     st->selfCircle_all = s.selfcircle_all;
     st->groups = s.groups; st->pairs = s.pairs; st->pair_bytes = s.pair_bytes; st->sam_bytes = s.sam_bytes;
     st->bytes_in = c->bytes_in; st->blocks = c->blocks;
-    if (!c->finished) {
-        if (!drop_last) {           // the newest group is final after all: release it
-            c->out_pairs.insert(c->out_pairs.end(), c->tail_pairs.begin(), c->tail_pairs.end());
-            c->out_sam.insert(c->out_sam.end(), c->tail_sam.begin(), c->tail_sam.end());
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (!c->finished) {
+            if (!drop_last && (!c->tail_pairs.empty() || !c->tail_sam.empty())) {      // the newest group is final after all: release it
+                mkt_ctx::Chunk t;
+                t.own_pairs.swap(c->tail_pairs); t.own_sam.swap(c->tail_sam);
+                c->ready.push_back(std::move(t));
+            }
+            c->tail_pairs.clear(); c->tail_sam.clear();
+            c->finished = true;
         }
-        c->tail_pairs.clear(); c->tail_sam.clear();
-        c->finished = true;
     }
+    c->cv.notify_all();
     return MKT_OK;
 }
 
@@ -820,6 +1116,15 @@ int mkt_ext_chrstat(mkt_ctx* c, int drop_last, char* out, size_t cap, size_t* le
 int mkt_reset(mkt_ctx* c) {
     if (!c) return MKT_E_ARG;
     HIPCHK(c, hipSetDevice(c->p.device));
+    {   // the streaming pipeline idle (an earlier asynchronous error is forgotten with the input it belonged to)
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->cv.wait(lk, [&] { return c->async_rc != MKT_OK || c->jobs.empty(); });
+        (void)sync_all(c);
+        c->jobs.clear(); c->ready.clear(); c->handed = mkt_ctx::Chunk(); c->handed_valid = false;
+        for (int i = 0; i < mkt_ctx::kIn; ++i) c->in[i].busy = false;
+        for (int i = 0; i < mkt_ctx::kOut; ++i) { c->outs[i].dev_busy = false; c->outs[i].host_busy = false; }
+        c->async_rc = MKT_OK; c->cur = 0; c->seq = 0; c->consumer_async = false;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fold_timing(c);
     HIPCHK(c, hipMemsetAsync(c->d_run, 0, sizeof(DevRun), c->stream));
@@ -832,7 +1137,7 @@ int mkt_reset(mkt_ctx* c) {
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;
-    c->out_pairs.clear(); c->out_sam.clear(); c->tail_pairs.clear(); c->tail_sam.clear();
+    c->tail_pairs.clear(); c->tail_sam.clear(); c->drained_pairs.clear(); c->drained_sam.clear();
     c->input_done = c->finished = false;
     c->bytes_in = 0; c->blocks = 0;
     return MKT_OK;

@@ -840,6 +840,68 @@ __global__ void k_run_advance(KArgs a) {
     if (threadIdx.x == 0 && r->err == 0) { a.run->groups += r->groups; a.run->sc += r->sc; a.run->emitted += r->emitted; }     // a failed block is re-run
 }
 
+// Streaming path, after k_finish: one output of the block (its .pairs or its .sam bytes, which sit in `nregions` slices of the
+// region buffer) -> ONE contiguous range in `dst`, with the bytes of the block's last group moved to the very end:
+//     dst = [ everything but the last group | last group ]
+// The host then copies one range over PCIe and holds back only that tail (quirk Q1) instead of editing 16 slices.
+// dst is 16-byte aligned: every lane stores one aligned 16-byte chunk, loaded from wherever its bytes come from.
+struct GatherArgs {
+    const BlockResult* res;
+    const uint8_t* src; uint64_t rcap;          // region buffer, bytes per region slice
+    uint8_t* dst; uint64_t dst_cap;
+    int32_t which;                              // 0: .pairs, 1: .sam
+};
+__global__ __launch_bounds__(256) void k_gather(GatherArgs g) {
+    __shared__ uint64_t pre[kMaxRegions + 1];
+    __shared__ uint64_t s_hole, s_tp;
+    const BlockResult* r = g.res;
+    if (r->err) return;                                               // a failed block is re-run
+    if (threadIdx.x == 0) {
+        const uint32_t nr = r->nregions ? r->nregions : 1u;
+        uint64_t acc = 0;
+        for (uint32_t q = 0; q < (uint32_t)kMaxRegions; ++q) { pre[q] = acc; if (q < nr) acc += g.which ? r->rsam[q] : r->rpair[q]; }
+        pre[kMaxRegions] = acc;
+        uint64_t tp = 0, hole = acc;
+        if (r->last.valid) {
+            tp = g.which ? r->last.sam_bytes : r->last.pair_bytes;
+            const uint32_t lr = r->last.region < nr ? r->last.region : 0u;
+            hole = pre[lr] + (g.which ? r->last.sam_off : r->last.pair_off);
+        }
+        s_hole = hole; s_tp = tp;
+    }
+    __syncthreads();
+    const uint64_t total = pre[kMaxRegions], tp = s_tp, hole = s_hole, body = total - tp;
+    if (total > g.dst_cap) return;                                    // the host sizes dst from the region buffer: cannot happen
+    auto src_of = [&](uint64_t x) -> const uint8_t* {                 // byte x of dst comes from ...
+        const uint64_t y = x < body ? (x < hole ? x : x + tp) : hole + (x - body);      // ... byte y of the concatenated slices
+        uint32_t q = 0;
+#pragma unroll
+        for (uint32_t k = 1; k < (uint32_t)kMaxRegions; ++k) q += (y >= pre[k]) ? 1u : 0u;      // slices are in order; empty ones share a prefix
+        return g.src + (uint64_t)q * g.rcap + (y - pre[q]);
+    };
+    for (uint64_t x0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16u; x0 < total; x0 += (uint64_t)gridDim.x * blockDim.x * 16u) {
+        const uint64_t x1 = x0 + 15u < total ? x0 + 15u : total - 1u;
+        const uint8_t* a = src_of(x0);
+        const uint8_t* b = src_of(x1);
+        if (x1 - x0 == 15u && (uint64_t)(b - a) == 15u) {            // the usual case: 16 contiguous source bytes
+            uint4 v;
+            __builtin_memcpy(&v, a, 16);
+            *reinterpret_cast<uint4*>(g.dst + x0) = v;
+        } else {
+            for (uint64_t x = x0; x <= x1; ++x) g.dst[x] = *src_of(x);
+        }
+    }
+}
+hipError_t launch_gather(const BlockResult* d_res, const uint8_t* src, uint64_t rcap, uint8_t* dst, uint64_t dst_cap, int which, uint64_t max_bytes, hipStream_t s) {
+    GatherArgs g;
+    g.res = d_res; g.src = src; g.rcap = rcap; g.dst = dst; g.dst_cap = dst_cap; g.which = which;
+    uint64_t chunks = (max_bytes + 15) / 16;
+    unsigned grid = (unsigned)((chunks + 255) / 256 < 2048 ? (chunks + 255) / 256 : 2048);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_gather, dim3(grid), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
 // End of the input: how many of the run's self-circle groups the reference would have LOGGED (quirk Q2: only its
 // thread 0's share of every batch reaches the .log).  The list never leaves the device.
 __global__ void k_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_group, uint64_t group_offset, uint64_t K_total, uint32_t ref_threads,

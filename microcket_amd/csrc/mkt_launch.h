@@ -60,6 +60,8 @@ hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s);
 hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s);
 uint32_t finish_chunk_tiles();
 hipError_t launch_finish(const KArgs& a, hipStream_t s);
+// streaming path: one output of the block (which: 0 .pairs, 1 .sam) from its region slices to one contiguous range, last group at the end
+hipError_t launch_gather(const BlockResult* d_res, const uint8_t* src, uint64_t rcap, uint8_t* dst, uint64_t dst_cap, int which, uint64_t max_bytes, hipStream_t s);
 hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_group, uint64_t group_offset, uint64_t K_total, uint32_t ref_threads,
                             unsigned long long* out, hipStream_t s);
 

@@ -7,15 +7,19 @@
 //
 // Environment (extensions, never needed by the microcket driver):
 //   MKT_DEVICE       HIP device ordinal (default 0)
-//   MKT_BLOCK_MB     SAM megabytes per GPU pass (default 256)
+//   MKT_BLOCK_MB     SAM megabytes per GPU pass (default 64)
+//   MKT_IO_THREADS   threads that read a regular input file / write big .sam chunks (default 8)
 //   MKT_TILES        auto | fast | small
 //   MKT_EXT=1        extensions (never change stdout / .sam / .log): also writes
 //                      <prefix>.<mode>.chrstat     chrA \t chrB \t count   (reported pairs per chromosome pair)
 //                      <prefix>.<mode>.dedup.stat  Total / Uniq / Dup of the pairs-level duplicate marking
 //                      <prefix>.<mode>.dups        0-based ordinals (input order) of the reported pairs that are duplicates
+#include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -70,40 +74,103 @@ int main(int argc, char* argv[]) {
 
     const char* e;
     p.device = (e = getenv("MKT_DEVICE")) ? atoi(e) : 0;
-    p.block_bytes = (uint64_t)((e = getenv("MKT_BLOCK_MB")) ? atoi(e) : 256) << 20;
+    p.block_bytes = (uint64_t)((e = getenv("MKT_BLOCK_MB")) ? atoi(e) : 64) << 20;
     p.tiles = MKT_TILES_AUTO;
     if ((e = getenv("MKT_TILES"))) p.tiles = !strcmp(e, "small") ? MKT_TILES_SMALL : !strcmp(e, "fast") ? MKT_TILES_FAST : MKT_TILES_AUTO;
 
     const bool ext = (e = getenv("MKT_EXT")) && e[0] == '1';
     if (ext) p.extensions = MKT_EXT_KEYS;
+    const bool verbose = (e = getenv("MKT_VERBOSE")) && e[0] == '1';     // wall-clock marks on stderr (diagnostics only)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (verbose) fprintf(stderr, "[mkt] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    };
     mkt_ctx* ctx = nullptr;
     int rc = mkt_create(&p, &ctx);
+    mark("context");
     if (rc != MKT_OK) {
         std::cerr << "Error: GPU context: " << mkt_strerror(rc) << ": " << mkt_last_error(nullptr) << "\n";
         return 20;
     }
-    auto pump = [&]() -> bool {
-        mkt_out o;
-        if (mkt_drain(ctx, &o) != MKT_OK) return false;
-        if (o.pairs_len && fwrite(o.pairs, 1, o.pairs_len, stdout) != o.pairs_len) return false;
-        if (fsam && o.sam_len && fwrite(o.sam, 1, o.sam_len, fsam) != o.sam_len) return false;
+    // Outputs: a writer thread takes the published chunks straight out of the library's pinned staging buffers
+    // (mkt_drain_wait) while this thread keeps reading; a slow consumer of stdout throttles the pipeline by itself.
+    // After a write error the chunks are still taken (and dropped) so that nothing upstream blocks.
+    int io_threads = (e = getenv("MKT_IO_THREADS")) ? atoi(e) : 8;
+    if (io_threads < 1) io_threads = 1;
+    { const unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)io_threads > hc) io_threads = (int)hc; }
+    auto write_all = [](int fd, const char* p, size_t n) -> bool {
+        while (n) {
+            const ssize_t k = write(fd, p, n);
+            if (k < 0) { if (errno == EINTR) continue; return false; }
+            p += k; n -= (size_t)k;
+        }
         return true;
     };
+    const int sam_fd = fsam ? fileno(fsam) : -1;
+    struct stat ssb;
+    const bool sam_regular = fsam && fstat(sam_fd, &ssb) == 0 && S_ISREG(ssb.st_mode);
+    std::atomic<int> write_failed{0}, drain_rc{0};
+    std::thread writer([&]() {
+        off_t sam_off = 0;
+        for (;;) {
+            mkt_out o;
+            int done = 0;
+            const int wrc = mkt_drain_wait(ctx, &o, &done);
+            if (wrc != MKT_OK) { drain_rc = wrc; break; }
+            if (!write_failed) {
+                if (o.pairs_len && !write_all(1, o.pairs, o.pairs_len)) write_failed = 1;
+                if (fsam && o.sam_len) {
+                    if (sam_regular && o.sam_len >= ((size_t)8 << 20) && io_threads > 1) {
+                        // the page-cache copy of one thread is a few GB/s: big chunks go out as disjoint pwrite slices
+                        const size_t slice = ((o.sam_len + (size_t)io_threads - 1) / (size_t)io_threads + 4095) & ~(size_t)4095;
+                        std::vector<std::thread> th;
+                        std::atomic<int> bad{0};
+                        for (size_t lo = 0; lo < o.sam_len; lo += slice) {
+                            const size_t hi = lo + slice < o.sam_len ? lo + slice : o.sam_len;
+                            th.emplace_back([&, lo, hi]() {
+                                size_t d = lo;
+                                while (d < hi) {
+                                    const ssize_t k = pwrite(sam_fd, o.sam + d, hi - d, sam_off + (off_t)d);
+                                    if (k < 0) { if (errno == EINTR) continue; bad = 1; break; }
+                                    d += (size_t)k;
+                                }
+                            });
+                        }
+                        for (auto& x : th) x.join();
+                        if (bad) write_failed = 1;
+                    } else if (sam_regular) {
+                        size_t d = 0;
+                        while (d < o.sam_len) {
+                            const ssize_t k = pwrite(sam_fd, o.sam + d, o.sam_len - d, sam_off + (off_t)d);
+                            if (k < 0) { if (errno == EINTR) continue; write_failed = 1; break; }
+                            d += (size_t)k;
+                        }
+                    } else if (!write_all(sam_fd, o.sam, o.sam_len)) write_failed = 1;
+                    sam_off += (off_t)o.sam_len;
+                }
+            }
+            if (done) break;
+        }
+    });
+    auto bail = [&](int code) -> int {       // leave through mkt_finish so that the writer thread sees `done`
+        mkt_stats tmp;
+        (void)mkt_finish(ctx, 1, 0, 0, &tmp);
+        writer.join();
+        return code;
+    };
     // Input goes straight into the library's pinned block (no staging copy).  A regular file is read by a few threads
-    // (pread of disjoint slices: one thread copies out of the page cache at ~5 GB/s); a pipe -- the driver's case,
+    // (pread of disjoint slices: one thread copies out of the page cache at a few GB/s); a pipe -- the driver's case,
     // bwa | sam2pairs /dev/stdin -- is read as it comes.
     const int fd = fileno(fin);
     struct stat sb;
     const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
     off_t fpos = regular ? lseek(fd, 0, SEEK_CUR) : 0;
     if (regular && fpos < 0) fpos = 0;
-    int io_threads = (e = getenv("MKT_IO_THREADS")) ? atoi(e) : 4;
-    if (io_threads < 1) io_threads = 1;
     for (;;) {
         char* win = nullptr;
         size_t cap = 0;
         rc = mkt_input_window(ctx, &win, &cap);
-        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
+        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return bail(21); }
         size_t got = 0;
         int last = 0;
         if (regular) {
@@ -120,31 +187,40 @@ int main(int argc, char* argv[]) {
                     size_t done = lo;
                     while (done < hi) {
                         const ssize_t k = pread(fd, win + done, hi - done, fpos + (off_t)done);
-                        if (k <= 0) { bad[(size_t)t] = 1; break; }
+                        if (k <= 0) { if (k < 0 && errno == EINTR) continue; bad[(size_t)t] = 1; break; }
                         done += (size_t)k;
                     }
                 });
             }
             for (auto& x : th) x.join();
-            for (int b : bad) if (b) { std::cerr << "Error: read input failed!\n"; return 10; }
+            for (int b : bad) if (b) { std::cerr << "Error: read input failed!\n"; return bail(10); }
             got = want;
             fpos += (off_t)want;
             last = fpos >= sb.st_size;
         } else {
-            got = fread(win, 1, cap, fin);
-            last = got < cap;
+            // a pipe hands over at most its buffer per read: keep reading until the window is full or the writer closes
+            while (got < cap) {
+                const ssize_t k = read(fd, win + got, cap - got);
+                if (k < 0) { if (errno == EINTR) continue; std::cerr << "Error: read input failed!\n"; return bail(10); }
+                if (k == 0) { last = 1; break; }
+                got += (size_t)k;
+            }
         }
         rc = mkt_submit_window(ctx, got, last);
-        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
-        if (!pump()) { std::cerr << "Error: write output failed!\n"; return 22; }
+        if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return bail(21); }
+        if (write_failed) { std::cerr << "Error: write output failed!\n"; return bail(22); }
         if (last) break;
     }
     fclose(fin);
+    mark("input read");
     mkt_stats st;
     rc = mkt_finish(ctx, 1, 0, 0, &st);
+    mark("finish");
+    writer.join();
+    mark("outputs written");
     if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
-    if (!pump()) { std::cerr << "Error: write output failed!\n"; return 22; }
-    fflush(stdout);
+    if (drain_rc) { std::cerr << "Error: " << mkt_strerror(drain_rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
+    if (write_failed) { std::cerr << "Error: write output failed!\n"; return 22; }
     if (fsam) fclose(fsam);
 
     std::ofstream flog((base + "2pairs.log").c_str());     // sam2pairs.cpp:195-219

@@ -68,7 +68,7 @@ def test_golden_vectors_through_the_c_abi(golden):
 @pytest.mark.parametrize("profile,pid,modes", [("unc", 0, ("unc",)), ("stress", 2, ("unc", "flash")), ("flash", 1, ("flash",))])
 def test_lean_geometries_byte_parity(profile, pid, modes, read_len):
     """The production kernels for 100 bp (32 KiB tiles) and 50-75 bp reads (16 KiB tiles): >= 2^18 groups through the
-    streaming path in 48 MiB blocks under MKT_TILES_AUTO; .log byte-identical, .pairs and .sam equal to the oracle's as line
+    streaming path in 16 MiB blocks under MKT_TILES_AUTO; .log byte-identical, .pairs and .sam equal to the oracle's as line
     multisets (same length + order-independent 64-bit checksum of the lines), few tiles left to the generic kernel."""
     _need_gpu()
     groups = (1 << 18) + (1 << 16) + 4321
@@ -79,8 +79,8 @@ def test_lean_geometries_byte_parity(profile, pid, modes, read_len):
     for mode in modes:
         for sam in (True, False):
             po, so, lo, ost = util.oracle_run(host, mode, 8, 0.5, 10, sam)
-            with m.Context(mode, 0.5, 10, sam, 8, device=0, block_bytes=48 << 20) as c:
-                p, s, st, log = c.run_bytes(host, chunk=32 << 20)
+            with m.Context(mode, 0.5, 10, sam, 8, device=0, block_bytes=16 << 20) as c:
+                p, s, st, log = c.run_bytes(host, chunk=24 << 20)
                 tm = c.timing()
             tag = (profile, mode, read_len, sam, tm.tiles, tm.deferred_tiles)
             assert log == lo, tag
