@@ -20,6 +20,11 @@ exchange is the group-count all_gather + 8-counter all_reduce at the end (quirks
 per launch over its HIP-event launch duration, against 8 TB/s HBM.
 `cpu_baseline`: the reference itself (oracle/_ref/sam2pairs.ref, built from /root/reference by
 oracle/Makefile) timed on this host on a bounded sample of the same data (first blocks).
+`end_to_end` (N = 1): SURVEY.md 8(d)'s metric -- the drop-in executable against the reference on that same sample FILE,
+process start to exit, sam=no and sam=yes; `speedup_vs_cpu_baseline` is that like-for-like ratio.
+`sam_yes`, `flash` (N = 1): the same resident path with the .sam pass-through on / in stitched mode, each with its own
+k_fast roofline.  `roofline.traffic` is imported from the committed rocprofv3 --pmc passes (profiles/), not measured in
+this process.
 """
 import argparse
 import json
@@ -39,13 +44,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(ctx, ds, sample_groups, threads):
-    """Times the reference (or, if absent, the C restatement) on the first blocks of the data set."""
+def cpu_baseline(ctx, ds, sample_groups, threads, mode="unc"):
+    """Times the reference (or, if absent, the C restatement) on the first blocks of the data set, and -- on the SAME file in
+    /dev/shm -- the drop-in executable (wall clock including process start, file reads, PCIe both ways and all writes):
+    SURVEY.md 8(d)'s end-to-end metric, sam=no and sam=yes.  Returns (cpu_baseline, end_to_end)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "sam2pairs.ref")
     port = os.path.join(ROOT, "oracle", "_build", "sam2pairs_oracle")
     exe, kind = (ref, "reference") if os.path.exists(ref) else (port, "port")
     if not os.path.exists(exe):
-        return None
+        return None, None
+    import microcket_amd as m
     tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     d = tempfile.mkdtemp(prefix="mkt_bench_", dir=tmpdir)
     path = os.path.join(d, "sample.sam")
@@ -59,24 +67,48 @@ def cpu_baseline(ctx, ds, sample_groups, threads):
                 nbytes += n
                 if groups >= sample_groups:
                     break
-        def run_ref(nthreads):
+
+        def run(binary, nthreads, sam, out):
             t0 = time.time()
-            with open(os.devnull, "wb") as null:
-                rc = subprocess.run([exe, path, "unc", os.path.join(d, "out"), str(nthreads), "0.5", "10", "no"], stdout=null,
+            with open(out, "wb") as o:
+                rc = subprocess.run([binary, path, mode, os.path.join(d, "out"), str(nthreads), "0.5", "10", sam], stdout=o,
                                     stderr=subprocess.PIPE).returncode
             return rc, time.time() - t0
-        rc, dt = run_ref(threads)
+
+        rc, dt = run(exe, threads, "no", os.devnull)
         if rc != 0:
-            return None
-        out = {"value": groups / dt, "unit": "read-pairs/s", "cores": threads if kind == "reference" else 1, "kind": kind,
-               "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input, sam=no, thread={threads}, {dt:.1f} s",
+            return None, None
+        cpu = {"value": groups / dt, "unit": "read-pairs/s", "cores": threads if kind == "reference" else 1, "kind": kind,
+               "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input in /dev/shm, sam=no, thread={threads}, {dt:.1f} s",
                "host_cpus": os.cpu_count()}
         many = min(os.cpu_count() or 1, 64)
         if kind == "reference" and many > threads:              # also at thread = min(nproc, 64)
-            rc2, dt2 = run_ref(many)
+            rc2, dt2 = run(exe, many, "no", os.devnull)
             if rc2 == 0:
-                out["more_threads"] = {"cores": many, "value": groups / dt2, "seconds": dt2}
-        return out
+                cpu["more_threads"] = {"cores": many, "value": groups / dt2, "seconds": dt2}
+        e2e = None
+        mine = m.exe_path()
+        if os.path.exists(mine):
+            e2e = {"unit": "read-pairs/s", "what": "the sam2pairs executables on the same file: wall clock from process start to exit, "
+                   "input read from /dev/shm, stdout to /dev/null, side files to /dev/shm; never `value`",
+                   "sample_pairs": groups, "sample_bytes": nbytes}
+            for sam in ("no", "yes"):
+                best = None
+                for _ in range(2):
+                    rcm, dtm = run(mine, threads, sam, os.devnull)
+                    if rcm == 0 and (best is None or dtm < best):
+                        best = dtm
+                if sam == "no":
+                    dref = dt
+                else:
+                    rcr, dref = run(exe, threads, "yes", os.devnull)
+                    if rcr != 0:
+                        dref = None
+                if best is not None:
+                    e2e["sam_" + sam] = {"mi355x": groups / best, "mi355x_seconds": best, "mi355x_GBps": nbytes / best / 1e9,
+                                         "cpu_" + kind: (groups / dref) if dref else None, "cpu_seconds": dref,
+                                         "speedup": (dref / best) if dref else None}
+        return cpu, e2e
     finally:
         try:
             for fn in os.listdir(d):
@@ -84,6 +116,41 @@ def cpu_baseline(ctx, ds, sample_groups, threads):
             os.rmdir(d)
         except OSError:
             pass
+
+
+def resident_leg(m, local, mode, sam, pairs, block_groups, read_len, steps, warmup, seed, tiles, barrier):
+    """One more resident workload on its own context + data set (sam=yes, flash mode): pairs/s and the k_fast roofline."""
+    ctx = m.Context(mode, 0.5, 10, sam, 8, device=local, tiles=tiles)
+    ds = ctx.dataset(seed, 0 if mode == "unc" else 1, pairs, block_groups, genome=0, read_len=read_len, lanes=1, tail_group=True)
+    try:
+        for _ in range(max(warmup, 1)):
+            for (p, n, _g) in ds.blocks:
+                ctx.submit_device(p, n)
+        ctx.sync(); ctx.reset(); ctx.reset_timing()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for (p, n, _g) in ds.blocks:
+                ctx.submit_device(p, n)
+        ctx.sync()
+        el = time.perf_counter() - t0
+        tm = ctx.timing()
+        ctx.reset()
+        for (p, n, _g) in ds.blocks:
+            ctx.submit_device(p, n)
+        st = ctx.finish(True)
+        out_b = st.pair_bytes + (st.sam_bytes if sam else 0)
+        algo = (ds.total_bytes + out_b) * steps
+        ach = algo / (tm.tile_kernel_ms / 1e3) / 1e9 if tm.tile_kernel_ms > 0 else 0.0
+        return {"value": ds.total_groups * steps / el, "unit": "read-pairs/s", "ms_per_step": el / steps * 1e3, "pairs": ds.total_groups,
+                "workload": f"{ds.total_groups} synthetic pairs, {mode} mode, sam={'yes' if sam else 'no'}, {ds.total_bytes / 1e9:.1f} GB resident",
+                "bytes_per_pair_in": ds.total_bytes / ds.total_groups, "bytes_per_pair_out": out_b / ds.total_groups,
+                "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "avg_launch_ms": tm.tile_kernel_ms / tm.tile_launches if tm.tile_launches else None,
+                             "tiles_left_to_generic_kernel": tm.deferred_tiles}}
+    finally:
+        ds.close()
+        ctx.close()
 
 
 def main():
@@ -100,6 +167,8 @@ def main():
     ap.add_argument("--dedup", default="yes", choices=["yes", "no"],
                     help="yes (BASELINE.json's metric, sam2pairs+dedup): every step also marks duplicate pairs and counts chromosome pairs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the sam=yes and flash resident legs")
+    ap.add_argument("--leg-pairs", type=int, default=32_000_000, help="read pairs of the sam=yes / flash legs")
     ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
@@ -240,9 +309,9 @@ def main():
                     traffic_src = f"profiles/{os.path.basename(cands[-1])}: traffic/algorithmic = {tj['traffic_over_algorithmic']:.3f} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
         except Exception:
             traffic, traffic_src = None, None
-        cpu = None
+        cpu, e2e = None, None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(ctx, ds, args.cpu_sample_pairs, 8)
+            cpu, e2e = cpu_baseline(ctx, ds, args.cpu_sample_pairs, 8, args.mode)
         result = {
             "metric": ("read-pairs/sec through sam2pairs+dedup" if dedup else "read-pairs/sec through sam2pairs") + " (150 bp PE, hg38 names, SAM text resident in HBM)",
             "value": value,
@@ -277,6 +346,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_unit": "bytes/launch",
+                "traffic_measured_in_this_run": False,
                 "traffic_source": traffic_src,
                 "launches": tm_launch,
                 "avg_launch_ms": tm_ms / tm_launch if tm_launch else None,
@@ -295,10 +365,28 @@ def main():
             result["sam2pairs_only"] = {"value": total_pairs / el2, "unit": "read-pairs/s", "ms_per_step": el2 / args.steps * 1e3,
                                         "note": "the same steps without the extensions: exactly the reference's behaviour and outputs",
                                         "roofline": {"achieved": ach2, "unit": "GB/s", "frac": ach2 / HBM_PEAK_GBS, "avg_launch_ms": ms2 / ln2 if ln2 else None}}
+        if e2e:
+            result["end_to_end"] = e2e
+            if e2e.get("sam_no", {}).get("speedup"):
+                result["speedup_vs_cpu_baseline"] = e2e["sam_no"]["speedup"]
+                result["speedup_note"] = "like for like: both executables on the same file, process start to exit (end_to_end.sam_no)"
         if cpu:
-            result["speedup_vs_cpu_baseline"] = value / cpu["value"]
+            result["kernel_only_ratio_vs_cpu_baseline"] = value / cpu["value"]
+            result["kernel_only_ratio_note"] = "`value` has its input resident in HBM and leaves its output there; the CPU run reads a file: NOT like for like"
     ds.close()
     ctx.close()
+    if world == 1 and not args.no_extra_legs and result is not None:
+        # the other shapes of the same path, each with its own k_fast roofline (the 94 GB data set above is released first)
+        legs_steps = max(1, min(args.steps, 5))
+        try:
+            if args.sam == "no":
+                result["sam_yes"] = resident_leg(m, local, args.mode, True, min(args.pairs, args.leg_pairs), args.block_groups, args.read_len, legs_steps,
+                                                 1, seed, tiles, barrier)
+            if args.mode == "unc":
+                result["flash"] = resident_leg(m, local, "flash", args.sam == "yes", min(args.pairs, args.leg_pairs), args.block_groups // 2, args.read_len,
+                                               legs_steps, 1, seed + 1, tiles, barrier)
+        except Exception as ex:      # an auxiliary leg never takes the headline down with it
+            result["extra_legs_error"] = repr(ex)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -246,6 +246,12 @@ int main(int argc, char* argv[]) {
         std::ofstream fc((base + ".chrstat").c_str());
         fc.write(txt.data(), (std::streamsize)len);
     }
-    mkt_destroy(ctx);
-    return 0;
+    mark("side files");
+    // Every output is on its way to the kernel's page cache / the pipe.  Tearing the context down (unpinning staging buffers,
+    // freeing HBM, unloading the runtime) costs ~0.1 s that the process exit does for free: MKT_CLEAN_EXIT=1 does it
+    // anyway (leak checkers).
+    if ((e = getenv("MKT_CLEAN_EXIT")) && e[0] == '1') { mkt_destroy(ctx); return 0; }
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);
 }
