@@ -38,7 +38,6 @@ struct FastCfg {
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
     static constexpr int HSTRIDE = HEADB + 4;        // row pitch: 33 dwords, so lanes reading the same column of their own rows hit 32 different banks
     static constexpr int HW = LCAP_ * HSTRIDE;       // bytes of the head store
-    static constexpr int OWN = 28 * LCAP_;           // output dwords the emitter's owner table covers (more: binary search)
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
     static_assert(LCAP_ <= 255, "line / group ordinals are 8 bit");
@@ -54,11 +53,8 @@ template <class Cfg>
 struct FastState {
     alignas(16) uint8_t win[Cfg::HW + 16];           // line heads, HEADB bytes per line, rows HSTRIDE apart
     // per line of the window
-    union Recs {
+    struct Recs {
         struct { uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP], right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP]; } f;
-        // after the group phase the records are dead: the emitter keeps here, per aligned output dword of the tile's
-        // .pairs bytes, the ordinal of the reported pair whose line holds the dword's first byte
-        uint8_t own[Cfg::OWN];
     } rc;
     uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HSTRIDE + (goff & 15)
     uint16_t goff[Cfg::LCAP];            // line start, window relative
@@ -443,32 +439,57 @@ template <class Cfg> MKT_HD uint8_t fast_pair_byte(const FastState<Cfg>& st, uin
     const uint32_t i = g.em_idx[fast_pair_find(st, k)];
     return fast_layout_byte(st, g.g_slot[i], k - g.x_pair[i]);
 }
-// owner table: the reported pair opened by line i owns every aligned output dword (head bytes h, then dword d at
-// byte h + 4 d) whose first byte lies in its line
-template <class Cfg> MKT_HD bool fast_own_fits(const FastState<Cfg>& st) { return st.sums.pair_bytes <= 4u * (uint32_t)Cfg::OWN; }
-template <class Cfg> MKT_HD void fast_own_fill(FastState<Cfg>& st, uint32_t i, uint32_t h) {
-    const auto& g = st.u.g;
-    if (!(g.g_info[i] & GI_EMIT)) return;
-    const uint32_t x = g.x_pair[i], e = x + g.g_plen[i];          // bytes [x, e) of the tile's output
-    if (e <= h) return;
-    const uint32_t dlo = x > h ? (x - h + 3u) >> 2 : 0u, dhi = (e - 1u - h) >> 2;
-    const uint8_t ord = g.x_emit[i];
-    for (uint32_t d = dlo; d <= dhi; ++d) st.rc.own[d] = ord;
+// ---- emit: ONE lane writes one whole .pairs line ------------------------------------------------------------
+// The line is five byte runs of this state object (see FastLayout).  The lane streams them through a 64-bit byte FIFO
+// and writes destination-aligned dwords; the bytes in front of the first aligned dword and behind the last one go out
+// as single bytes (neighbouring lines own the rest of those dwords).  ~20 instructions per output dword for the one
+// lane that runs them, instead of a layout lookup per byte on every lane of the workgroup.
+MKT_HD uint32_t state_load4(const uint8_t* base, uint32_t off) {       // four bytes at any offset, from aligned dwords
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(base);
+    const uint32_t i = off >> 2;
+    const uint32_t lo = w[i], hi = w[i + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, off & 3u);
+#else
+    const uint32_t sh = (off & 3u) * 8u;
+    return sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+#endif
 }
-// four consecutive output bytes k .. k+3 (little endian) starting in the line of reported pair `ord`; bytes at or past
-// `total` read as 0
-template <class Cfg> MKT_HD uint32_t fast_pair_bytes4(const FastState<Cfg>& st, uint32_t k, uint32_t total, uint32_t ord) {
+template <class Cfg> MKT_HD void fast_emit_line(const FastState<Cfg>& st, uint32_t slot, uint32_t plen, uint8_t* dst) {
     const auto& g = st.u.g;
-    uint32_t i = g.em_idx[ord], o = k - g.x_pair[i], plen = g.g_plen[i];
-    FastLayout<Cfg> L = fast_layout(st, g.g_slot[i]);
-    uint32_t w = 0;
-    for (uint32_t b = 0; b < 4u; ++b) {
-        if (k + b >= total) break;
-        if (o >= plen) { ++ord; i = g.em_idx[ord]; L = fast_layout(st, g.g_slot[i]); o = 0; plen = g.g_plen[i]; }    // next line (lines are >= 14 bytes)
-        w |= (uint32_t)fast_layout_byte(st, L, o) << (8u * b);
-        ++o;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(&st);
+    const uint32_t w = (uint32_t)(st.win - base);
+    const uint32_t e0 = g.l_e0[slot], e1 = g.l_e1[slot], e2 = g.l_e2[slot], e3 = g.l_e3[slot];
+    const uint32_t rs[5] = {w + g.l_qa[slot], w + g.l_ca[slot], (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litA[slot][0]) - base),
+                            w + g.l_cb[slot], (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litB[slot][0]) - base)};
+    const uint32_t rl[5] = {e0, e1 - e0, e2 - e1, e3 - e2, plen - e3};
+    const uint32_t a = (uint32_t)((uintptr_t)dst & 3u);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst - a);            // the aligned dword that holds the line's first byte
+    uint64_t acc = 0;
+    uint32_t cnt = a;                                              // its low `a` bytes belong to the line before
+    bool first = a != 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 5; ++r) {
+        for (uint32_t k = 0; k < rl[r]; k += 4u) {
+            uint32_t x = state_load4(base, rs[r] + k);
+            const uint32_t take = rl[r] - k < 4u ? rl[r] - k : 4u;
+            if (take < 4u) x &= (1u << (8u * take)) - 1u;
+            acc |= (uint64_t)x << (8u * cnt);
+            cnt += take;
+            if (cnt >= 4u) {
+                const uint32_t v = (uint32_t)acc;
+                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) b[q] = (uint8_t)(v >> (8u * q)); first = false; }
+                else *d = v;
+                ++d; acc >>= 32; cnt -= 4u;
+            }
+        }
     }
-    return w;
+    {   // what is left: cnt (< 4) bytes of the last, shared dword
+        uint8_t* b = reinterpret_cast<uint8_t*>(d);
+        for (uint32_t q = first ? a : 0u; q < cnt; ++q) b[q] = (uint8_t)((uint32_t)acc >> (8u * q));
+    }
 }
 
 }  // namespace mkt

@@ -663,32 +663,23 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         // ---- emit ----------------------------------------------------------------------------------
         const uint32_t total = st.sums.pair_bytes;
         uint8_t* const dst = s_out.pairs + st.base.pair_bytes;
-        const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u);              // bytes before the first aligned dword
-        const uint32_t h = head < total ? head : total;
-        const bool own = fast_own_fits(st);
         for (uint32_t i = first_idx + tid; i < end_idx; i += NT) {
             fast_account(st, s_out, t, i);
             fast_last(st, G, &a.tile_last[t], i);
-            if (own) fast_own_fill(st, i, h);
+        }
+        // .pairs: one lane per reported pair writes its whole line (fast_emit_line)
+        if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
+            const auto& g = st.u.g;
+            for (uint32_t e = tid; e < st.sums.emitted; e += NT) {
+                const uint32_t i = g.em_idx[e];
+                fast_emit_line(st, g.g_slot[i], g.g_plen[i], dst + g.x_pair[i]);
+            }
         }
         __syncthreads();
         // counters and error bits of the tile are final here; flushed once per workgroup (9 global atomics per TILE on one
         // cache line would queue up behind each other)
         if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
         if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
-        {
-            if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
-                // one lane per 4-byte-aligned output dword; the partial dwords at both ends go out as bytes
-                if (tid < (int)h) dst[tid] = fast_pair_byte(st, (uint32_t)tid);
-                const uint32_t ndw = (total - h + 3u) >> 2;
-                for (uint32_t d = tid; d < ndw; d += NT) {
-                    const uint32_t k = h + (d << 2);
-                    const uint32_t w = fast_pair_bytes4(st, k, total, own ? (uint32_t)st.rc.own[d] : fast_pair_find(st, k));
-                    if (k + 4u <= total) *reinterpret_cast<uint32_t*>(dst + k) = w;
-                    else for (uint32_t b = 0; k + b < total; ++b) dst[k + b] = (uint8_t)(w >> (8u * b));
-                }
-            }
-        }
         if (P.write_sam && st.sums.sam_bytes) {
             const uint64_t gos = st.base.sam_bytes;
             if (gos + st.sums.sam_bytes <= s_out.sam_cap) {

@@ -69,15 +69,18 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     tile_groups[t] = run.groups;
     TileLast tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t i = first_idx; i < end_idx; ++i) { fast_account(st, out, t, i); fast_last(st, G, &tl, i); }
-    // the kernel writes aligned dwords (fast_pair_bytes4) plus byte-wise ends: exercise both forms
-    for (uint32_t k = 0; k < s.pair_bytes; ++k) out.pairs[run.pair_bytes + k] = fast_pair_byte(st, k);
-    const uint32_t hb = t % 4 < s.pair_bytes ? t % 4 : (uint32_t)s.pair_bytes;    // the kernel: alignment of the claimed output range
-    const bool own = fast_own_fits(st) && (t & 4) == 0;                         // ... owner table, or binary search when it does not fit
-    if (own) for (uint32_t i = first_idx; i < end_idx; ++i) fast_own_fill(st, i, hb);
-    for (uint32_t k = hb; k < s.pair_bytes; k += 4) {
-        const uint32_t w = fast_pair_bytes4(st, k, s.pair_bytes, own ? (uint32_t)st.rc.own[(k - hb) >> 2] : fast_pair_find(st, k));
-        for (uint32_t b = 0; b < 4 && k + b < s.pair_bytes; ++b)
-            if (out.pairs[run.pair_bytes + k + b] != (uint8_t)(w >> (8 * b))) { res.err |= 0x4000; }
+    // the kernel: one lane per reported pair writes its whole line (fast_emit_line: aligned dwords + single bytes at the ends);
+    // here last line first, between sentinels, then checked byte by byte against the per-byte reference fast_pair_byte
+    {
+        uint8_t* o = out.pairs + run.pair_bytes;
+        const uint8_t before = run.pair_bytes ? o[-1] : 0, after = o[s.pair_bytes];
+        for (uint32_t k = 0; k < s.pair_bytes; ++k) o[k] = 0xEE;
+        for (uint32_t e = s.emitted; e-- > 0;) {
+            const uint32_t i = g.em_idx[e];
+            fast_emit_line(st, g.g_slot[i], g.g_plen[i], o + g.x_pair[i]);
+        }
+        for (uint32_t k = 0; k < s.pair_bytes; ++k) if (o[k] != fast_pair_byte(st, k)) res.err |= 0x4000;
+        if ((run.pair_bytes && o[-1] != before) || o[s.pair_bytes] != after) res.err |= 0x4000;
     }
     if (P.write_sam)
         for (uint32_t i = first_idx; i < NLe; ++i)
