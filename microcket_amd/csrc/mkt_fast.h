@@ -34,7 +34,8 @@ struct FastCfg {
     static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
     static constexpr int MW = (W + 63) / 64 + 3;
     static constexpr int GCAP = 96;                  // emitting groups per tile (more: generic kernel)
-    static constexpr int NV16 = (W + 15) / 16 + 8;   // 16-byte vectors of the window (+ padding)
+    static constexpr int NV16 = (W + 15) / 16;       // 16-byte vectors of the window
+    static constexpr int HMW = (NV16 + 63) / 64;     // 64-bit words of the "vector holds a newline" bitmap
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
     static constexpr int HSTRIDE = HEADB + 4;        // row pitch: 33 dwords, so lanes reading the same column of their own rows hit 32 different banks
     static constexpr int HW = LCAP_ * HSTRIDE;       // bytes of the head store
@@ -45,7 +46,7 @@ struct FastCfg {
 };
 
 // why a tile is left to the generic kernel (low byte of FastState::abn; any value != 0 defers)
-enum { AB_LCAP = 1, AB_LONG, AB_TAB, AB_PREV_WS, AB_PREV_HEAD, AB_NO_PREV, AB_OPEN_GROUP, AB_LAST_LINE, AB_GCAP, AB_PAIR_BYTES };
+enum { AB_LCAP = 1, AB_LONG, AB_TAB, AB_PREV_WS, AB_PREV_HEAD, AB_NO_PREV, AB_OPEN_GROUP, AB_LAST_LINE, AB_GCAP, AB_PAIR_BYTES, AB_SHORT_LINE };
 
 constexpr uint8_t LB_EMIT = 8;          // line belongs to an emitting group (its bytes go to the .sam)
 
@@ -56,13 +57,14 @@ struct FastState {
     struct Recs {
         struct { uint32_t pos[Cfg::LCAP], lclip[Cfg::LCAP], rclip[Cfg::LCAP], mappable[Cfg::LCAP], right0[Cfg::LCAP], left1[Cfg::LCAP], right1[Cfg::LCAP]; } f;
     } rc;
-    uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HSTRIDE + (goff & 15)
-    uint16_t goff[Cfg::LCAP];            // line start, window relative
+    uint16_t hv16[Cfg::LCAP];            // window vector that holds the newline in front of line i (line table); the head row starts there
+    uint16_t off16[Cfg::LCAP];           // line start in the head store: i * HSTRIDE + (1 + byte of that newline in its vector), set while parsing
+    uint16_t goff[Cfg::LCAP];            // line start, window relative: 16 * hv16 + the same; may be >= the window length for the last entry
     uint16_t flag[Cfg::LCAP];
     uint8_t qn_off[Cfg::LCAP], qn_len[Cfg::LCAP], rn_off[Cfg::LCAP], rn_len[Cfg::LCAP], segCnt[Cfg::LCAP], bits[Cfg::LCAP];
     union alignas(16) Phase {
         struct {                                               // while parsing
-            uint16_t nl16[Cfg::NV16];                          // newline bits, one u16 per 16 window bytes (line table only)
+            uint64_t hitmap[Cfg::HMW + 1];                     // bit v: window vector v (16 bytes) holds a newline (scan phase -> line table)
             alignas(8) uint16_t hmask[Cfg::LCAP][Cfg::HCH];    // per line: whitespace bits of its head chunks
         } m;
         struct {                                               // afterwards, indexed by the group's first line / by line
@@ -84,7 +86,7 @@ struct FastState {
     // extension: this workgroup's cache of the chromosome table, kept across its tiles.  One word per entry (name bytes
     // in bits 0..47, table slot in 48..60, valid in 63), so that a lane never pairs one entry's name with another's slot
     uint64_t cc[64];
-    uint32_t NL, first_idx, end_idx, abn, last_line_end, nslot;
+    uint32_t NL, first_idx, end_idx, abn, last_line_end, nslot, c_t0, c_t1;
     uint32_t cnt[C_COUNT];
     TileSums sums, base;                  // base: ABSOLUTE positions in OutPtrs::pairs / sam / sc
     uint32_t region_pair0, region_sam0, region_id;
@@ -124,7 +126,7 @@ template <class Cfg> MKT_HD uint32_t fast_chr_slot(FastState<Cfg>& st, ChrTab* t
     return s;
 }
 template <class Cfg> MKT_HD void fast_reset(FastState<Cfg>& st) {
-    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown; st.nslot = 0;
+    st.NL = 0; st.first_idx = 0; st.end_idx = 0; st.abn = 0; st.last_line_end = kUnknown; st.nslot = 0; st.c_t0 = 0; st.c_t1 = 0;
     for (int k = 0; k < 4; ++k) st.m_emit[k] = 0;
     st.region_pair0 = 0; st.region_sam0 = 0; st.region_id = 0;
     for (int k = 0; k < (int)C_COUNT; ++k) st.cnt[k] = 0;
@@ -147,13 +149,13 @@ MKT_HD uint32_t ws_bits16_ref(const uint8_t* win, uint32_t r0, uint32_t wlen) {
 template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t i, uint64_t& ws0, uint64_t& ws1) {
     const uint64_t* row = reinterpret_cast<const uint64_t*>(st.u.m.hmask[i]);
     const uint64_t A = row[0], B = row[1];
-    const uint32_t sh = st.goff[i] & 15u;
+    const uint32_t sh = (uint32_t)st.off16[i] - i * (uint32_t)Cfg::HSTRIDE;        // 0 (first line of a block) .. 16
     ws0 = sh ? ((A >> sh) | (B << (64u - sh))) : A;
     ws1 = B >> sh;
 }
 // one head chunk: the 16 text bytes at window offset r0 (multiple of 16); bytes at or past the block end read as 0
 template <class Cfg> MKT_HD void fast_head_chunk_ref(FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G, uint32_t i, uint32_t c) {
-    const uint32_t r0 = (st.goff[i] & ~15u) + 16u * c;
+    const uint32_t r0 = 16u * ((uint32_t)st.hv16[i] + c);
     uint32_t m = 0;
     for (uint32_t b = 0; b < 16u; ++b) {
         const uint64_t g = (uint64_t)G.w0 + r0 + b;
@@ -164,19 +166,70 @@ template <class Cfg> MKT_HD void fast_head_chunk_ref(FastState<Cfg>& st, const u
     st.u.m.hmask[i][c] = (uint16_t)m;
 }
 
+// ---- where line i starts inside its head row ------------------------------------------------------------
+// Row i begins with the 16-byte vector that holds the newline in front of the line (the scan only recorded WHICH vectors
+// hold one).  Returns 1 + the byte of that newline (1..16); 0 for the line that opens the block (nothing in front of
+// it).  *multi: the vector holds a second newline, i.e. a line of fewer than 16 bytes that the table does not know.
+MKT_HD uint32_t nl_flags_exact(uint32_t x) {                      // 0x80 in every byte of x that is '\n'
+    const uint32_t y = (x ^ 0x0A0A0A0Au), z = y & 0x7F7F7F7Fu;
+    return ~((z + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu);
+}
+template <class Cfg> MKT_HD uint32_t fast_row_start(const FastState<Cfg>& st, const TileGeom& G, uint32_t i, bool* multi) {
+    *multi = false;
+    if (i == 0u && G.w0 == 0u) return 0u;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE]);
+    const uint32_t f0 = nl_flags_exact(row[0]), f1 = nl_flags_exact(row[1]), f2 = nl_flags_exact(row[2]), f3 = nl_flags_exact(row[3]);
+    // one bit per byte, byte order: flags sit at bit 7 of every byte, so dword j shifted right by (3 - j) interleaves them
+    const uint32_t m = (f0 >> 3) | (f1 >> 2) | (f2 >> 1) | f3;    // byte b of dword j -> bit 8 b + 4 + j
+    *multi = (m & (m - 1u)) != 0u;
+    const uint32_t a0 = f0 ? ctz32(f0) >> 3 : 4u, a1 = f1 ? 4u + (ctz32(f1) >> 3) : 8u, a2 = f2 ? 8u + (ctz32(f2) >> 3) : 12u,
+                   a3 = f3 ? 12u + (ctz32(f3) >> 3) : 16u;
+    const uint32_t p = f0 ? a0 : (f1 ? a1 : (f2 ? a2 : a3));       // first newline of the vector (16: none -- cannot happen)
+    return p + 1u;
+}
+// distance from the start of line i to its newline when that lies inside the head (else any value >= 128): the next table
+// entry names the vector, the exact byte comes from this line's own row
+template <class Cfg> MKT_HD uint32_t fast_line_len_in_head(const FastState<Cfg>& st, uint32_t i, uint32_t goff) {
+    const uint32_t hv = st.hv16[i], hvn = st.hv16[i + 1u];
+    if (hvn * 16u >= goff + 128u || hvn >= hv + (uint32_t)Cfg::HCH) return 0xFFFFu;
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE + 16u * (hvn - hv)]);
+    for (uint32_t d = 0; d < 4u; ++d) {
+        uint32_t f = nl_flags_exact(row[d]);
+        // the line's own leading newline sits in this very vector when hvn == hv: skip what lies in front of the line
+        while (f) {
+            const uint32_t pos = hvn * 16u + 4u * d + (ctz32(f) >> 3);
+            if (pos >= goff) return pos - goff;
+            f &= f - 1u;
+        }
+    }
+    return 0xFFFFu;
+}
+
 // ---- parse line i ------------------------------------------------------------------------------
 template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
-    const uint32_t gl = G.w0 + st.goff[i];                         // line start in the block
-    const uint32_t off = st.off16[i];                              // ... and in the head store
-    if (gl >= G.t0 && (i == 0 || G.w0 + st.goff[i - 1] < G.t0)) st.first_idx = i;
-    if (gl >= G.t1 && (i == 0 || G.w0 + st.goff[i - 1] < G.t1)) st.end_idx = i;
+    bool multi;
+    const uint32_t soff = fast_row_start(st, G, i, &multi);
+    if (multi) st.abn = AB_SHORT_LINE;
+    const uint32_t goff = 16u * (uint32_t)st.hv16[i] + soff;
+    const uint32_t off = i * (uint32_t)Cfg::HSTRIDE + soff;        // line start in the head store
+    st.goff[i] = (uint16_t)goff;
+    st.off16[i] = (uint16_t)off;
+    const uint32_t gl = G.w0 + goff;                               // ... and in the block
+    if (gl >= G.w1) {                                              // the newline is the window's last byte: no line of this window
+        st.bits[i] = LB_CUT;                                       // (always the table's last entry; the line before it ends right here)
+        if (i + 1u != st.NL) st.abn = AB_SHORT_LINE;
+        return;
+    }
     Rec r;
     uint64_t ws0, ws1;
     fast_head_ws(st, i, ws0, ws1);
-    const uint32_t le = fast_line_end(st, G, i);                   // from the line table: no newline bitmap needed
-    const uint32_t room = (uint32_t)Cfg::HEADB - (st.goff[i] & 15u), reach = tv.n - gl;
+    // the line's end: from the next table entry; the last entry ends at the block end or beyond the window
+    uint32_t L;
+    if (i + 1u < st.NL) L = fast_line_len_in_head(st, i, goff);
+    else L = st.last_line_end == kUnknown ? 0xFFFFu : st.last_line_end - gl;
+    const uint32_t room = (uint32_t)Cfg::HEADB - soff, reach = tv.n - gl;
     rec_clear(r, off);
-    const int pf = parse_record_core(tv, off, P, r, ws0, ws1, le == kUnknown ? 0xFFFFu : le - gl, room < reach ? room : reach, reach);
+    const int pf = parse_record_core(tv, off, P, r, ws0, ws1, L, room < reach ? room : reach, reach);
     if (pf != PF_OK) {
         if (gl >= G.t1 && i + 1 == st.NL && G.w1 < tv.n) st.bits[i] = LB_CUT;    // last halo line: ignored (a group reaching it is deferred)
         else { st.bits[i] = 0; st.abn = AB_LONG; }                       // fields beyond the head: generic kernel
@@ -192,10 +245,12 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     if (tv.win[off + r.qn_off + r.qn_len] != '\t' || tv.win[off + r.rn_off + r.rn_len] != '\t') st.abn = AB_TAB;
     if (i > 0) {
         // same QNAME token as the line before: its first token must start at its first byte
-        const uint32_t poff = st.off16[i - 1];
+        bool pm;
+        const uint32_t psoff = fast_row_start(st, G, i - 1u, &pm);        // (its own lane sets off16[i - 1] in this same phase: recompute)
+        const uint32_t poff = (i - 1u) * (uint32_t)Cfg::HSTRIDE + psoff;
         const uint32_t ql = r.qn_len;
         if (is_ws(tv.win[poff])) st.abn = AB_PREV_WS;
-        else if (ql + 1u > (uint32_t)Cfg::HEADB - (st.goff[i - 1] & 15u)) st.abn = AB_PREV_HEAD;          // beyond the previous line's head
+        else if (ql + 1u > (uint32_t)Cfg::HEADB - psoff) st.abn = AB_PREV_HEAD;          // beyond the previous line's head
         else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql])) b |= LB_EQPREV;
     }
     st.bits[i] = b;

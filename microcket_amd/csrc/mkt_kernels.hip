@@ -409,14 +409,12 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
     __shared__ FastState<Cfg> st;
     __shared__ ScanScratch scan;
     constexpr int NVEC = (Cfg::W + 15) / 16;
-    constexpr int VPT = (NVEC + NT - 1) / NT;
     static_assert(Cfg::LCAP <= NT, "one line per thread in the sums");
     const int tid0 = threadIdx.x;
     const Params P = a.P;
     const uint32_t n = a.n;
     __shared__ OutPtrs s_out;
     const uint32_t region = blockIdx.x & (uint32_t)(a.nregions - 1);
-    uint16_t* nlmask = st.u.m.nl16;
 #if defined(MKT_STAMPS)
     unsigned long long stamp_prev_ = 0;
 #endif
@@ -437,10 +435,13 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         const uint32_t nvec = (wlen + 15u) >> 4;
         const TextView tv = fast_view(st, a.text, n, G);
 
-        // ---- newline bits (one u16 per 16 bytes) of the window: the text streams through registers only
+        // ---- scan: which 16-byte vectors of the window hold a newline.  The text streams through registers only; per vector
+        //      a 3-op-per-dword "some byte == '\n'" test and one ballot: 64 vectors per bitmap word, in window order.
         {
             constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread
             constexpr int BATCH = MKT_LOAD_BATCH;
+            const uint32_t tail = (G.w1 >= n) ? (wlen & 15u) : 0u;      // bytes of a partial last vector (only the block's last window has one)
+            const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
             for (int k0 = 0; k0 < LPT; k0 += BATCH) {
                 uint4 x[BATCH];
@@ -451,27 +452,23 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                     // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
                     if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
-                // ... then the math.  One vector in ~21 holds a newline: an exact 4-op-per-dword "any byte == '\\n'" test
-                // sorts them out, and only those go through the flag packing (each lane loops over its own hits)
-                uint32_t hit = 0;
 #pragma unroll
-                for (int k = 0; k < BATCH; ++k) {
+                for (int k = 0; k < BATCH; ++k) {              // ... then the math
+                    if (k0 + k >= LPT) continue;
                     const uint32_t v = tid + (k0 + k) * NT;
-                    if (k0 + k >= LPT || v >= nvec) continue;
-                    if (has_nl(x[k].x) | has_nl(x[k].y) | has_nl(x[k].z) | has_nl(x[k].w)) hit |= 1u << k;
-                    else nlmask[v] = 0;
-                }
-                while (hit) {
-                    const uint32_t k = (uint32_t)__builtin_ctz(hit);
-                    hit &= hit - 1u;
-                    uint4 y = x[0];
+                    uint4 y = x[k];
+                    if (tail && v == nvec - 1u) {              // bytes past the end of the block are not text
+                        uint32_t* w = reinterpret_cast<uint32_t*>(&y);
 #pragma unroll
-                    for (int j = 1; j < BATCH; ++j) if (k == (uint32_t)j) y = x[j];
-                    const uint32_t v = tid + ((uint32_t)k0 + k) * NT;
-                    uint32_t mnl = pack16(nl_flags(y.x), nl_flags(y.y), nl_flags(y.z), nl_flags(y.w));
-                    const uint32_t r0 = v << 4;
-                    if (r0 + 16u > wlen) mnl &= (1u << (wlen - r0)) - 1u;      // bytes past the end of the window / block
-                    nlmask[v] = (uint16_t)mnl;
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t lo = (uint32_t)d * 4u;
+                            w[d] = tail >= lo + 4u ? w[d] : (tail > lo ? (w[d] & ((1u << ((tail - lo) * 8u)) - 1u)) : 0u);
+                        }
+                    }
+                    const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
+                    const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
+                    const uint64_t bm = __ballot((z & 0x80808080u) != 0u);
+                    if (lane == 0 && (uint32_t)((k0 + k) * (NT / 64) + wv) < (uint32_t)Cfg::HMW) st.u.m.hitmap[(k0 + k) * (NT / 64) + wv] = bm;
                 }
             }
         }
@@ -479,54 +476,29 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         STAMP(1);
         STOP_AFTER(1)
 
-        // ---- line table ----------------------------------------------------------------------------
-        {
-            auto line_bits = [&](uint32_t v) -> uint32_t {     // a newline at the window's last byte opens no line
-                uint32_t m = nlmask[v];
-                const uint32_t r0 = v << 4;
-                if (r0 + 16u > wlen - 1u) { const uint32_t keep = wlen - 1u > r0 ? wlen - 1u - r0 : 0u; m &= keep >= 16u ? 0xFFFFu : ((1u << keep) - 1u); }
-                return m;
-            };
-            // this lane's VPT consecutive vectors as 64-bit words of newline bits (4 vectors per word), kept in registers
-            constexpr int NW = (VPT + 3) / 4;
-            const uint32_t v0 = tid * VPT;
-            uint64_t mw[NW];
-            uint32_t cnt = 0, total;
+        // ---- line table: one entry per newline vector, in window order (one wave; a bitmap word per lane)
+        if (tid < 64) {
+            static_assert(Cfg::HMW <= 64, "one bitmap word per lane of one wave");
+            uint64_t m = tid < Cfg::HMW ? st.u.m.hitmap[tid] : 0ull;
+            const uint32_t cnt = (uint32_t)__popcll(m);
+            uint32_t inc = cnt;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) mw[w] = 0;
-#pragma unroll
-            for (int k = 0; k < VPT; ++k) {
-                const uint32_t m = v0 + (uint32_t)k < nvec ? line_bits(v0 + (uint32_t)k) : 0u;
-                mw[k >> 2] |= (uint64_t)m << (16 * (k & 3));
-            }
-#pragma unroll
-            for (int w = 0; w < NW; ++w) cnt += (uint32_t)__popcll(mw[w]);
-            uint32_t ex = cnt;
-            block_exscan1(ex, total, scan);
-            const uint32_t lead = G.w0 == 0 ? 1u : 0u;
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (tid >= d) inc += y; }
+            const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+            const uint32_t lead = G.w0 == 0 ? 1u : 0u;             // the block's first line has no newline in front of it
             const uint32_t NLt = total + lead;
             if (NLt > (uint32_t)Cfg::LCAP) {
                 if (tid == 0) { st.abn = AB_LCAP; st.NL = 0; }
             } else {
-                uint32_t idx = ex + lead;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    uint64_t m = mw[w];
-                    while (m) {
-                        const uint32_t b = (uint32_t)__builtin_ctzll(m);
-                        const uint32_t r = ((v0 + 4u * (uint32_t)w) << 4) + b + 1u;
-                        st.goff[idx] = (uint16_t)r;
-                        st.off16[idx] = (uint16_t)(idx * (uint32_t)Cfg::HSTRIDE + (r & 15u));
-                        ++idx;
-                        m &= m - 1ull;
-                    }
+                uint32_t idx = inc - cnt + lead;
+                while (m) {
+                    st.hv16[idx++] = (uint16_t)(((uint32_t)tid << 6) + (uint32_t)__builtin_ctzll(m));
+                    m &= m - 1ull;
                 }
                 if (tid == 0) {
-                    if (lead) { st.goff[0] = 0; st.off16[0] = 0; }
+                    if (lead) st.hv16[0] = 0;
                     st.NL = NLt; st.first_idx = NLt; st.end_idx = NLt;
-                    // end of the table's last line: the window's last byte when that is a newline
-                    const bool nl_last = (nlmask[(wlen - 1u) >> 4] >> ((wlen - 1u) & 15u)) & 1u;
-                    st.last_line_end = nl_last ? G.w1 - 1u : (G.w1 >= n ? n : kUnknown);
+                    st.last_line_end = G.w1 >= n ? n : kUnknown;   // the last entry's line runs to the block end / out of the window
                 }
             }
         }
@@ -545,7 +517,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 q[k] = make_uint4(0, 0, 0, 0);
                 if (it < NL * (uint32_t)Cfg::HCH) {
                     const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
-                    const uint64_t g0 = (uint64_t)G.w0 + (st.goff[i] & ~15u) + (c << 4);
+                    const uint64_t g0 = (uint64_t)G.w0 + (((uint32_t)st.hv16[i] + c) << 4);
                     if (g0 < n) q[k] = *reinterpret_cast<const uint4*>(a.text + g0);
                 }
             }
@@ -554,7 +526,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                 const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
                 if (it >= NL * (uint32_t)Cfg::HCH) continue;
                 const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
-                const uint64_t g0 = (uint64_t)G.w0 + (st.goff[i] & ~15u) + (c << 4);
+                const uint64_t g0 = (uint64_t)G.w0 + (((uint32_t)st.hv16[i] + c) << 4);
                 uint4 x = q[k];
                 if (g0 < n && g0 + 16u > n) {                              // last vector of the block: clear the bytes past the end
                     const uint32_t keep = (uint32_t)(n - g0);              // 1..15
@@ -587,14 +559,21 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             const bool sv = (lb & LB_SURVIVE) != 0;
             const uint64_t b_s = __ballot(sv), b_e = __ballot((lb & LB_EQPREV) != 0);
             const uint64_t b_1 = __ballot(sv && (fl & 64u)), b_2 = __ballot(sv && !(fl & 64u) && (fl & 128u));
-            if ((tid & 63) == 0) { const int w = tid >> 6; st.m_surv[w] = b_s; st.m_eqp[w] = b_e; st.m_r1[w] = b_1; st.m_r2[w] = b_2; }
+            // lines are in text order: the tile's own lines are [NL - #(start >= t0), NL - #(start >= t1))
+            const uint32_t gs = i < NL ? (uint32_t)st.goff[i] : 0u;
+            const uint64_t b_t0 = __ballot(i < NL && G.w0 + gs >= G.t0), b_t1 = __ballot(i < NL && G.w0 + gs >= G.t1);
+            if ((tid & 63) == 0) {
+                const int w = tid >> 6; st.m_surv[w] = b_s; st.m_eqp[w] = b_e; st.m_r1[w] = b_1; st.m_r2[w] = b_2;
+                if (b_t0) atomicAdd(&st.c_t0, (uint32_t)__popcll(b_t0));
+                if (b_t1) atomicAdd(&st.c_t1, (uint32_t)__popcll(b_t1));
+            }
         }
         __syncthreads();
         STAMP(3);
         STOP_AFTER(3)
         const uint32_t NLe = fast_nle(st);
-        const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe;
-        const uint32_t end_idx = st.end_idx < NLe ? st.end_idx : NLe;
+        const uint32_t first_idx = NL - st.c_t0 < NLe ? NL - st.c_t0 : NLe;
+        const uint32_t end_idx = NL - st.c_t1 < NLe ? NL - st.c_t1 : NLe;
         {   // which surviving lines open a group
             const uint32_t i = (uint32_t)tid;
             bool s0 = false;

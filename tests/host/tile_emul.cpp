@@ -28,17 +28,26 @@ static bool lean_tile(FastState<FC>& st, const uint8_t* text, uint32_t n, const 
     memset(&st.u, 0, sizeof st.u);
     const TextView tv = fast_view(st, text, n, G);
     const uint8_t* win = text + G.w0;                          // the kernel streams these bytes through registers
+    // scan + line table: one entry per 16-byte vector of the window that holds a newline (plus the block's first line)
     uint32_t NL = 0;
-    auto add_line = [&](uint32_t r) { st.goff[NL] = (uint16_t)r; st.off16[NL] = (uint16_t)(NL * FC::HSTRIDE + (r & 15u)); ++NL; };
-    if (G.w0 == 0) add_line(0);
-    for (uint32_t r = 0; r + 1 < wlen; ++r)
-        if (win[r] == '\n') { if (NL == (uint32_t)FC::LCAP) return false; add_line(r + 1); }
-    st.last_line_end = win[wlen - 1] == '\n' ? G.w1 - 1u : (G.w1 >= n ? n : kUnknown);
+    if (G.w0 == 0) st.hv16[NL++] = 0;
+    for (uint32_t v = 0; v * 16u < wlen; ++v) {
+        bool hit = false;
+        for (uint32_t b = 0; b < 16u && v * 16u + b < wlen; ++b) hit = hit || win[v * 16u + b] == '\n';
+        if (hit) { if (NL == (uint32_t)FC::LCAP) return false; st.hv16[NL++] = (uint16_t)v; }
+    }
+    st.last_line_end = G.w1 >= n ? n : kUnknown;
     // line heads with their whitespace bits (k_fast: one lane per 16-byte chunk)
     for (uint32_t i = 0; i < NL; ++i)
         for (uint32_t c = 0; c < (uint32_t)FC::HCH; ++c) fast_head_chunk_ref(st, text, n, G, i, c);
-    st.NL = NL; st.first_idx = NL; st.end_idx = NL;
+    st.NL = NL;
     for (uint32_t i = 0; i < NL; ++i) fast_parse(st, tv, P, G, i);
+    // the tile's own lines (the kernel: two ballots over "line starts at or after t0 / t1")
+    st.first_idx = NL; st.end_idx = NL;
+    for (uint32_t i = NL; i-- > 0;) {
+        if (G.w0 + st.goff[i] >= G.t0) st.first_idx = i;
+        if (G.w0 + st.goff[i] >= G.t1) st.end_idx = i;
+    }
     const uint32_t NLe = fast_nle(st);
     const uint32_t first_idx = st.first_idx < NLe ? st.first_idx : NLe, end_idx = st.end_idx < NLe ? st.end_idx : NLe;
     fast_build_masks(st);                                      // the kernel: ballots after fast_parse
