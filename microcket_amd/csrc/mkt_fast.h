@@ -83,6 +83,9 @@ struct FastState {
     } u;
     // one bit per line of the window (ballots of the parse / start phases)
     uint64_t m_surv[4], m_eqp[4], m_r1[4], m_r2[4], m_start[4], m_emit[4];
+    // the tile's own group starts in line order: logical wave w of the start phase fills start_list[64 w, 64 w + start_cnt[w])
+    uint8_t start_list[256];
+    uint32_t start_cnt[4];
     // extension: this workgroup's cache of the chromosome table, kept across its tiles.  One word per entry (name bytes
     // in bits 0..47, table slot in 48..60, valid in 63), so that a lane never pairs one entry's name with another's slot
     uint64_t cc[64];
@@ -404,11 +407,11 @@ template <class Cfg> MKT_HD uint32_t fast_line_sam(const FastState<Cfg>& st, con
 }
 
 // ---- account for the group opened by line i (counters, self-circle entry) ------------------------
-template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs& out, uint32_t tile, uint32_t i) {
+template <class Cfg, bool COUNT = true> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs& out, uint32_t tile, uint32_t i) {
     const uint32_t info = st.u.g.g_info[i];
     if (!(info & GI_START)) return;
     const uint32_t counter = info & GI_COUNTER;
-    if (counter) lds_add(&st.cnt[counter], 1u);
+    if (COUNT && counter) lds_add(&st.cnt[counter], 1u);       // (the kernel counts by ballots instead)
     if (counter == C_SELFCIRCLE) {
         uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
         if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
