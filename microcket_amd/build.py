@@ -62,6 +62,15 @@ def build_stamps_lib(name="libmkt_hip_stamps.so", defines=("-DMKT_STAMPS",)):
     return out
 
 
+def build_variant(name, kernel_src=None, defines=()):
+    """Experiment builds: another kernel source file and / or extra -D flags -> microcket_amd/<name> (select it with MKT_LIB)."""
+    out = os.path.join(HERE, name)
+    srcs = [kernel_src or os.path.join(CSRC, "mkt_kernels.hip"), os.path.join(CSRC, "mkt_capi.cpp")]
+    _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", *defines, "-Wno-unused-function", "-I" + CSRC,
+          "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", out])
+    return out
+
+
 def build_exe(force=False):
     src = os.path.join(CSRC, "sam2pairs_main.cpp")
     if force or _newer(EXE, [src, LIB] + _headers()):

@@ -33,7 +33,10 @@ template <int TILE_, int HB_, int HF_, int LCAP_>
 struct FastCfg {
     static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
     static constexpr int MW = (W + 63) / 64 + 3;
-    static constexpr int GCAP = 96;                  // emitting groups per tile (more: generic kernel)
+#ifndef MKT_GCAP
+#define MKT_GCAP 96
+#endif
+    static constexpr int GCAP = MKT_GCAP;            // emitting groups per tile (more: generic kernel)
     static constexpr int NV16 = (W + 15) / 16;       // 16-byte vectors of the window
     static constexpr int HMW = (NV16 + 63) / 64;     // 64-bit words of the "vector holds a newline" bitmap
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
@@ -83,9 +86,6 @@ struct FastState {
     } u;
     // one bit per line of the window (ballots of the parse / start phases)
     uint64_t m_surv[4], m_eqp[4], m_r1[4], m_r2[4], m_start[4], m_emit[4];
-    // the tile's own group starts in line order: logical wave w of the start phase fills start_list[64 w, 64 w + start_cnt[w])
-    uint8_t start_list[256];
-    uint32_t start_cnt[4];
     // extension: this workgroup's cache of the chromosome table, kept across its tiles.  One word per entry (name bytes
     // in bits 0..47, table slot in 48..60, valid in 63), so that a lane never pairs one entry's name with another's slot
     uint64_t cc[64];
@@ -407,11 +407,11 @@ template <class Cfg> MKT_HD uint32_t fast_line_sam(const FastState<Cfg>& st, con
 }
 
 // ---- account for the group opened by line i (counters, self-circle entry) ------------------------
-template <class Cfg, bool COUNT = true> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs& out, uint32_t tile, uint32_t i) {
+template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs& out, uint32_t tile, uint32_t i) {
     const uint32_t info = st.u.g.g_info[i];
     if (!(info & GI_START)) return;
     const uint32_t counter = info & GI_COUNTER;
-    if (COUNT && counter) lds_add(&st.cnt[counter], 1u);       // (the kernel counts by ballots instead)
+    if (counter) lds_add(&st.cnt[counter], 1u);
     if (counter == C_SELFCIRCLE) {
         uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
         if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];

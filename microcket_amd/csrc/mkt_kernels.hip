@@ -11,7 +11,6 @@
 //
 // No MFMA: this is byte/integer work bounded by HBM bandwidth (DESIGN.md has the byte budget).
 #include <hip/hip_runtime.h>
-#include <type_traits>
 #include "mkt_launch.h"
 
 // tile geometry of the fast configuration (the lean and the generic kernel must agree on TILE)
@@ -405,8 +404,11 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 // tile that needs one is appended to the defer list and produces nothing here.
 typedef FastCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, MKT_LEAN_LCAP> CfgLean;
 
+#ifndef MKT_WPS
+#define MKT_WPS 4          // waves per SIMD the lean kernel is compiled for (workgroups of 4 waves per CU)
+#endif
 template <class Cfg>
-__global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per SIMD: four 36 KB workgroups per CU
+__global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves per SIMD: four 36 KB workgroups per CU
     __shared__ FastState<Cfg> st;
     __shared__ ScanScratch scan;
     constexpr int NVEC = (Cfg::W + 15) / 16;
@@ -439,56 +441,40 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
 
         // ---- scan: which 16-byte vectors of the window hold a newline.  The text streams through registers only; per vector
         //      a 3-op-per-dword "some byte == '\n'" test and one ballot: 64 vectors per bitmap word, in window order.
-        //      Lane k of a wave keeps the ballot of round k; the words go to LDS once, at the end.
         {
             constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread
             constexpr int BATCH = MKT_LOAD_BATCH;
-            static_assert(LPT <= 64, "one lane per round keeps its ballot");
-            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6), lane = (uint32_t)tid & 63u;
-            auto scan_window = [&](auto full_c) {
-                constexpr bool FULL = decltype(full_c)::value;         // every load of every lane lies inside the block, no partial last vector
-                const uint32_t tail = FULL ? 0u : ((G.w1 >= n) ? (wlen & 15u) : 0u);
-                uint64_t mine = 0;
+            const uint32_t tail = (G.w1 >= n) ? (wlen & 15u) : 0u;      // bytes of a partial last vector (only the block's last window has one)
+            const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
-                for (int k0 = 0; k0 < LPT; k0 += BATCH) {
-                    uint4 x[BATCH];
+            for (int k0 = 0; k0 < LPT; k0 += BATCH) {
+                uint4 x[BATCH];
 #pragma unroll
-                    for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
-                        if (k0 + k >= LPT) continue;
-                        const uint32_t v = tid + (k0 + k) * NT;
-                        if (FULL) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
-                        else {
-                            x[k] = make_uint4(0, 0, 0, 0);
-                            // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
-                            if (v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < BATCH; ++k) {              // ... then the math
-                        if (k0 + k >= LPT) continue;
-                        uint4 y = x[k];
-                        if (!FULL && tail && (uint32_t)tid + (uint32_t)(k0 + k) * NT == nvec - 1u) {      // bytes past the end of the block are not text
-                            uint32_t* w = reinterpret_cast<uint32_t*>(&y);
-#pragma unroll
-                            for (int d = 0; d < 4; ++d) {
-                                const uint32_t lo = (uint32_t)d * 4u;
-                                w[d] = tail >= lo + 4u ? w[d] : (tail > lo ? (w[d] & ((1u << ((tail - lo) * 8u)) - 1u)) : 0u);
-                            }
-                        }
-                        const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
-                        const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
-                        uint64_t bm = __ballot((z & 0x80808080u) != 0u);
-                        // vectors at or past the end of the window (a block's first and last windows are shorter) hold no line start
-                        const uint32_t w64 = ((uint32_t)(k0 + k) * (NT / 64) + wv) << 6;
-                        const uint32_t nv = nvec > w64 ? nvec - w64 : 0u;
-                        if (nv < 64u) bm &= (1ull << nv) - 1ull;
-                        if (lane == (uint32_t)(k0 + k)) mine = bm;
-                    }
+                for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
+                    const uint32_t v = tid + (k0 + k) * NT;
+                    x[k] = make_uint4(0, 0, 0, 0);
+                    // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
+                    if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
-                if (lane < (uint32_t)LPT && lane * (NT / 64) + wv < (uint32_t)Cfg::HMW) st.u.m.hitmap[lane * (NT / 64) + wv] = mine;
-            };
-            if ((uint64_t)G.w0 + (uint64_t)LPT * NT * 16u <= (uint64_t)n) scan_window(std::true_type{});
-            else scan_window(std::false_type{});
+#pragma unroll
+                for (int k = 0; k < BATCH; ++k) {              // ... then the math
+                    if (k0 + k >= LPT) continue;
+                    const uint32_t v = tid + (k0 + k) * NT;
+                    uint4 y = x[k];
+                    if (tail && v == nvec - 1u) {              // bytes past the end of the block are not text
+                        uint32_t* w = reinterpret_cast<uint32_t*>(&y);
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            const uint32_t lo = (uint32_t)d * 4u;
+                            w[d] = tail >= lo + 4u ? w[d] : (tail > lo ? (w[d] & ((1u << ((tail - lo) * 8u)) - 1u)) : 0u);
+                        }
+                    }
+                    const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
+                    const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
+                    const uint64_t bm = __ballot((z & 0x80808080u) != 0u);
+                    if (lane == 0 && (uint32_t)((k0 + k) * (NT / 64) + wv) < (uint32_t)Cfg::HMW) st.u.m.hitmap[(k0 + k) * (NT / 64) + wv] = bm;
+                }
+            }
         }
         __syncthreads();
         STAMP(1);
@@ -567,13 +553,18 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         __syncthreads();
         STOP_AFTER(9)
 
-        // Logical lanes: the waves swap roles from tile to tile.  Parsing keeps logical waves 0..2 busy (one lane per line);
-        // the group pipeline below runs on logical wave 3, so the four SIMDs of the CU share the work of a tile evenly
-        // whatever SIMD a wave happens to sit on.
+        // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
+#if defined(MKT_ROTATE)
+        // logical lanes: the waves swap roles from tile to tile (parsing fills logical waves 0..2, the group phase runs on
+        // logical waves 2 and 3), so that the four SIMDs of the CU share a tile's work whatever SIMD a wave sits on
         const uint32_t ltid = ((uint32_t)tid + ((rot & 3u) << 6)) & (uint32_t)(NT - 1);
-        const uint32_t lw = ltid >> 6, lane = (uint32_t)tid & 63u;
-        const uint64_t lt_mask = (1ull << lane) - 1ull;
         ++rot;
+        const uint32_t rr_id = (ltid >> 6) >= 2u ? (ltid & 63u) * 2u + ((ltid >> 6) - 2u) : 0xFFFFFFu;
+#else
+        const uint32_t ltid = (uint32_t)tid;
+        (void)rot;
+        const uint32_t rr_id = ((uint32_t)tid >> 6) < (uint32_t)MKT_RR ? ((uint32_t)tid & 63u) * MKT_RR + ((uint32_t)tid >> 6) : 0xFFFFFFu;
+#endif
         {   // one lane per line (LCAP < NT); the line masks are the waves' ballots
             static_assert(Cfg::LCAP <= NT, "one parse lane per line");
             const uint32_t i = ltid;
@@ -585,8 +576,8 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
             // lines are in text order: the tile's own lines are [NL - #(start >= t0), NL - #(start >= t1))
             const uint32_t gs = i < NL ? (uint32_t)st.goff[i] : 0u;
             const uint64_t b_t0 = __ballot(i < NL && G.w0 + gs >= G.t0), b_t1 = __ballot(i < NL && G.w0 + gs >= G.t1);
-            if (lane == 0) {
-                st.m_surv[lw] = b_s; st.m_eqp[lw] = b_e; st.m_r1[lw] = b_1; st.m_r2[lw] = b_2;
+            if ((tid & 63) == 0) {
+                const uint32_t w = ltid >> 6; st.m_surv[w] = b_s; st.m_eqp[w] = b_e; st.m_r1[w] = b_1; st.m_r2[w] = b_2;
                 if (b_t0) atomicAdd(&st.c_t0, (uint32_t)__popcll(b_t0));
                 if (b_t1) atomicAdd(&st.c_t1, (uint32_t)__popcll(b_t1));
             }
@@ -597,122 +588,97 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
         const uint32_t NLe = fast_nle(st);
         const uint32_t first_idx = NL - st.c_t0 < NLe ? NL - st.c_t0 : NLe;
         const uint32_t end_idx = NL - st.c_t1 < NLe ? NL - st.c_t1 : NLe;
-        {   // which surviving lines open a group; the tile's own group starts also go, in line order, into start_list
+        {   // which surviving lines open a group
             const uint32_t i = ltid;
             bool s0 = false;
             if (!st.abn && i >= first_idx && i < NLe && mask_bit(st.m_surv, i)) s0 = fast_is_start(st, tv, G, i);
             const uint64_t b = __ballot(s0);
-            const bool own = s0 && i < end_idx;
-            const uint64_t bo = __ballot(own);
-            if (own) st.start_list[(lw << 6) + (uint32_t)__popcll(bo & lt_mask)] = (uint8_t)i;
-            if (lane == 0) { st.m_start[lw] = b; st.start_cnt[lw] = (uint32_t)__popcll(bo); }
+            if ((tid & 63) == 0) st.m_start[ltid >> 6] = b;
         }
+        __syncthreads();
+        if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * MKT_RR) fast_group(st, tv, P, G, i);
         __syncthreads();
         STAMP(4);
         STOP_AFTER(4)
+        STAMP(5);
 
-        // ---- group pipeline (logical wave 3): one lane per QNAME group -- classification, the tile's sums by ballots and
-        //      one wave scan, output ranges, accounting, the .pairs lines.  No workgroup barrier inside (sam=no).
-        const bool gwave = lw == 3u;
-        if (gwave) {
+        // ---- tile sums: groups / emitted / self-circles / .pairs bytes per group, .sam bytes per line --
+        {
             auto& g = st.u.g;
-            const uint32_t c0 = st.start_cnt[0], c1 = c0 + st.start_cnt[1], c2 = c1 + st.start_cnt[2], nst = c2 + st.start_cnt[3];
-            uint32_t em_base = 0, sc_base = 0, pb_base = 0, mine = 0;        // mine: lane c counts the groups of counter c
-            if (!st.abn) {
-                for (uint32_t b0 = 0; b0 < nst; b0 += 64u) {
-                    const uint32_t L = b0 + lane;
-                    const bool have = L < nst;
-                    uint32_t i = 0, info = 0, plen = 0;
-                    if (have) {
-                        const uint32_t w = (L >= c0 ? 1u : 0u) + (L >= c1 ? 1u : 0u) + (L >= c2 ? 1u : 0u);
-                        const uint32_t base = w == 0u ? 0u : (w == 1u ? c0 : (w == 2u ? c1 : c2));
-                        i = st.start_list[(w << 6) + (L - base)];
-                        fast_group(st, tv, P, G, i);
-                        info = g.g_info[i]; plen = g.g_plen[i];
-                    }
-                    const uint32_t counter = info & GI_COUNTER;
-                    const uint64_t be = __ballot((info & GI_EMIT) != 0u), bs = __ballot((info & GI_START) && counter == C_SELFCIRCLE);
-                    uint32_t inc = plen;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= (uint32_t)d) inc += y; }
-                    if (have) {
-                        const uint32_t xe = em_base + (uint32_t)__popcll(be & lt_mask);
-                        g.x_grp[i] = (uint8_t)L; g.x_emit[i] = (uint8_t)xe; g.x_sc[i] = (uint8_t)(sc_base + (uint32_t)__popcll(bs & lt_mask));
-                        g.x_pair[i] = (uint16_t)(pb_base + inc - plen);
-                        if (info & GI_EMIT) g.em_idx[xe] = (uint8_t)i;
-                    }
-#pragma unroll
-                    for (uint32_t c = 1; c < (uint32_t)C_COUNT; ++c) { const uint64_t bc = __ballot((info & GI_START) && counter == c); if (lane == c) mine += (uint32_t)__popcll(bc); }
-                    em_base += (uint32_t)__popcll(be); sc_base += (uint32_t)__popcll(bs);
-                    pb_base += (uint32_t)__shfl((int)inc, 63, 64);
+            const uint32_t i = first_idx + tid;
+            uint64_t ca = 0, cb = 0;
+            uint32_t info = 0;
+            if (i < NLe && !st.abn) {
+                if (i < end_idx) {
+                    info = g.g_info[i];
+                    if (info & GI_START) ca += 1ull;
+                    if (info & GI_EMIT) ca += 1ull << 16;
+                    if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ca += 1ull << 32;
+                    cb = g.g_plen[i];
+                }
+                if (P.write_sam) cb |= (uint64_t)fast_line_sam(st, G, i) << 32;
+            }
+            uint64_t ea = ca, eb = cb, ta, tb;
+            block_exscan2(ea, eb, ta, tb, scan);
+            if (i < NLe && !st.abn) {
+                g.x_sam[i] = (uint32_t)(eb >> 32);
+                if (i < end_idx) {
+                    g.x_grp[i] = (uint8_t)(ea & 0xFFu); g.x_sc[i] = (uint8_t)((ea >> 32) & 0xFFu); g.x_emit[i] = (uint8_t)((ea >> 16) & 0xFFu);
+                    g.x_pair[i] = (uint16_t)(eb & 0xFFFFu);
+                    if (info & GI_EMIT) g.em_idx[(ea >> 16) & 0xFFu] = (uint8_t)i;
                 }
             }
-            if (lane == 0) {
-                st.sums.groups = nst; st.sums.emitted = em_base; st.sums.sc = sc_base; st.sums.pair_bytes = pb_base; st.sums.sam_bytes = 0;
-                if (pb_base > 0xFFFFu) st.abn = AB_PAIR_BYTES;               // 16-bit in-tile offsets
+            if (tid == 0) {
+                st.sums.groups = (uint32_t)(ta & 0xFFFFu); st.sums.emitted = (uint32_t)((ta >> 16) & 0xFFFFu); st.sums.sc = (uint32_t)((ta >> 32) & 0xFFFFu);
+                st.sums.pair_bytes = (uint32_t)tb; st.sums.sam_bytes = tb >> 32;
+                if ((uint32_t)tb > 0xFFFFu) st.abn = AB_PAIR_BYTES;          // 16-bit in-tile offsets
             }
-            if (lane < (uint32_t)C_COUNT) st.cnt[lane] = mine;
         }
-        if (P.write_sam) {      // .sam bytes per surviving line of the reported groups (m_emit): a workgroup-wide scan
-            __syncthreads();
-            const uint32_t i = first_idx + (uint32_t)tid;
-            uint32_t len = 0, total;
-            if (!st.abn && i < NLe) len = fast_line_sam(st, G, i);
-            uint32_t ex = len;
-            block_exscan1(ex, total, scan);
-            if (!st.abn && i < NLe) st.u.g.x_sam[i] = ex;
-            if (tid == 0) st.sums.sam_bytes = total;
-            __syncthreads();
-        }
+        __syncthreads();
         STAMP(6);
         STOP_AFTER(6)
-        if (gwave) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (st.abn) {                                         // leave the whole tile to the generic kernel
-                if (lane == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
-            } else {
-                // ---- output ranges: ONE 64-bit atomic on the tile's region cursor (a second one for .sam / self-circles)
-                if (lane == 0) {
-                    const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
-                    st.region_id = region;
-                    if (e) lds_or(&st.abn, e << 8);
-                    a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const auto& g = st.u.g;
-                const uint32_t c0 = st.start_cnt[0], c1 = c0 + st.start_cnt[1], c2 = c1 + st.start_cnt[2], nst = st.sums.groups;
-                for (uint32_t L = lane; L < nst; L += 64u) {
-                    const uint32_t w = (L >= c0 ? 1u : 0u) + (L >= c1 ? 1u : 0u) + (L >= c2 ? 1u : 0u);
-                    const uint32_t base = w == 0u ? 0u : (w == 1u ? c0 : (w == 2u ? c1 : c2));
-                    const uint32_t i = st.start_list[(w << 6) + (L - base)];
-                    fast_account<Cfg, false>(st, s_out, t, i);
-                    fast_last(st, G, &a.tile_last[t], i);
-                }
-                // .pairs: one lane per reported pair writes its whole line (fast_emit_line)
-                const uint32_t total = st.sums.pair_bytes;
-                if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
-                    uint8_t* const dst = s_out.pairs + st.base.pair_bytes;
-                    for (uint32_t e = lane; e < st.sums.emitted; e += 64u) {
-                        const uint32_t i = g.em_idx[e];
-                        fast_emit_line(st, g.g_slot[i], g.g_plen[i], dst + g.x_pair[i]);
-                    }
-                }
-                // counters and error bits of the tile are final here; flushed once per workgroup (9 global atomics per TILE
-                // on one cache line would queue up behind each other)
-                if (lane < (uint32_t)C_COUNT) wg_cnt[lane] += st.cnt[lane];
-                if (lane == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
+        if (st.abn) {                                         // leave the whole tile to the generic kernel
+            if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
+            __syncthreads();
+            continue;
+        }
+
+        // ---- output ranges --------------------------------------------------------------------------
+        if (tid == 0) {
+            const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
+            st.region_id = region;
+            if (e) lds_or(&st.abn, e << 8);
+        } else if (tid == 4) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
+        __syncthreads();
+        STAMP(7);
+        STOP_AFTER(7)
+
+        // ---- emit ----------------------------------------------------------------------------------
+        const uint32_t total = st.sums.pair_bytes;
+        uint8_t* const dst = s_out.pairs + st.base.pair_bytes;
+        for (uint32_t i = first_idx + ltid; i < end_idx; i += NT) {
+            fast_account(st, s_out, t, i);
+            fast_last(st, G, &a.tile_last[t], i);
+        }
+        // .pairs: one lane per reported pair writes its whole line (fast_emit_line)
+        if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
+            const auto& g = st.u.g;
+            for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted; e += NT) {      // (the two waves the accounting left idle)
+                const uint32_t i = g.em_idx[e];
+                fast_emit_line(st, g.g_slot[i], g.g_plen[i], dst + g.x_pair[i]);
             }
         }
-        STAMP(7);
-        if (P.write_sam) {
-            __syncthreads();
-            if (!(st.abn & 0xFFu) && st.sums.sam_bytes) {
+        __syncthreads();
+        // counters and error bits of the tile are final here; flushed once per workgroup (9 global atomics per TILE on one
+        // cache line would queue up behind each other)
+        if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
+        if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
+        if (P.write_sam && st.sums.sam_bytes) {
             const uint64_t gos = st.base.sam_bytes;
             if (gos + st.sums.sam_bytes <= s_out.sam_cap) {
                 // one wave per emitting line, straight from the text in global memory (L2): 16-byte stores on
                 // destination-aligned chunks, single bytes at the two ends
-                const int wv = tid >> 6;
+                const int wv = tid >> 6, lane = tid & 63;
                 for (uint32_t i = first_idx + wv; i < NLe; i += NT / 64) {
                     if (!mask_bit(st.m_emit, i)) continue;
                     const uint8_t* src = a.text + G.w0 + st.goff[i];
@@ -720,7 +686,7 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                     uint8_t* dst = s_out.sam + gos + st.u.g.x_sam[i];
                     const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
                     const uint32_t h = head < len ? head : len;
-                    if (lane < h) dst[lane] = src[lane];
+                    if ((uint32_t)lane < h) dst[lane] = src[lane];
                     const uint32_t nv = (len - h) >> 4;
                     for (uint32_t v = lane; v < nv; v += 64) {
                         const uint32_t o = h + (v << 4);
@@ -729,9 +695,8 @@ __global__ __launch_bounds__(NT, 4) void k_fast(KArgs a) {      // 4 waves per S
                         *reinterpret_cast<uint4*>(dst + o) = x;
                     }
                     const uint32_t t0 = h + (nv << 4);
-                    if (lane < len - t0) dst[t0 + lane] = src[t0 + lane];
+                    if ((uint32_t)lane < len - t0) dst[t0 + lane] = src[t0 + lane];
                 }
-            }
             }
         }
         __syncthreads();                                           // every lane is done with this tile's state
@@ -987,7 +952,7 @@ uint32_t finish_chunk_tiles() { return NTF; }
 // 1/4 element on average); every element then looks back inside its run for an equal FULL key (exact;
 // hash ties only cost time, and within a run earlier in memory = earlier in the input).
 constexpr int DD_WG = 256;
-constexpr uint64_t kKeyMask1 = 0xFFFFFFFFC0000000ull;          // posB + the two strand bits of KeyRec::k1
+constexpr uint64_t kKeyMask1 = 0xFFFFFFFFC000FFFFull;          // posB, the two strand bits and the lane (0 unless MKT_EXT_LANES) of KeyRec::k1
 
 __device__ inline bool key_eq(const KeyRec& x, const KeyRec& y) { return x.k0 == y.k0 && (x.k1 & kKeyMask1) == (y.k1 & kKeyMask1); }
 
@@ -1100,6 +1065,95 @@ hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* wo
     e = hipMemsetAsync(flags, 0, n, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dd_mark, dim3(1024), dim3(256), 0, s, keys, (const uint64_t*)rA, n, run_mask, flags, d_res);
+    return hipGetLastError();
+}
+
+// ---- sharded duplicate marking (one context per GPU): hash-partitioned exchange of the key space ----------------
+// Every rank sends each key record to rank mix64(key) % world (RCCL all_to_all over xGMI, microcket_amd/shard.py), so equal
+// keys meet on one rank, which marks them with the kernels above.  k_part_* is the stable partition in front of that:
+// chromosome slots are rewritten to ids that are the same on every rank (lut, from the exchanged name tables), records are
+// grouped by destination IN INPUT ORDER (so that "first in input order wins" survives the exchange: ranks hold contiguous
+// shards, segments arrive in rank order), and perm[j] remembers where record j went (the flags come back the same way).
+constexpr uint32_t kMaxWorld = 16;
+__device__ inline KeyRec part_remap(KeyRec r, const uint16_t* lut) {
+    if (lut) {
+        const uint64_t a = lut[(r.k0 >> 45) & (kChrSlots - 1u)], b = lut[(r.k0 >> 32) & (kChrSlots - 1u)];
+        r.k0 = (a << 45) | (b << 32) | (r.k0 & 0xFFFFFFFFull);
+    }
+    return r;
+}
+__device__ inline uint32_t part_dest(const KeyRec& r, uint32_t world) { return (uint32_t)(mix64(r.k0 ^ mix64(r.k1 & kKeyMask1)) % world); }
+__global__ __launch_bounds__(DD_WG) void k_part_hist(const KeyRec* keys, uint64_t n, uint64_t per, const uint16_t* lut, uint32_t world, uint32_t* hist, uint32_t G) {
+    __shared__ uint32_t cnt[kMaxWorld];
+    if (threadIdx.x < kMaxWorld) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j = b + threadIdx.x; j < e; j += DD_WG) atomicAdd(&cnt[part_dest(part_remap(keys[j], lut), world)], 1u);
+    __syncthreads();
+    if (threadIdx.x < kMaxWorld) hist[threadIdx.x * G + blockIdx.x] = cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(DD_WG) void k_part_scatter(const KeyRec* keys, uint64_t n, uint64_t per, const uint16_t* lut, uint32_t world, const uint32_t* hist,
+                                                       uint32_t G, KeyRec* send, uint32_t* perm) {
+    __shared__ uint32_t base[kMaxWorld];
+    __shared__ uint32_t wcnt[DD_WG / 64][kMaxWorld];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < (int)kMaxWorld) base[tid] = hist[tid * G + blockIdx.x];
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j0 = b; j0 < e; j0 += DD_WG) {            // sub-tiles in input order keep the partition stable
+        const uint64_t j = j0 + tid;
+        const bool live = j < e;
+        KeyRec r;
+        r.k0 = r.k1 = r.ord = 0;
+        if (live) r = part_remap(keys[j], lut);
+        const uint32_t d = live ? part_dest(r, world) : kMaxWorld;
+        uint32_t rank = 0;
+        for (uint32_t dd = 0; dd < world; ++dd) {
+            const uint64_t m = __ballot(d == dd);
+            if (d == dd) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wv][dd] = __popcll(m);
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t o = base[d] + rank;
+            for (int w = 0; w < wv; ++w) o += wcnt[w][d];
+            send[o] = r;
+            perm[j] = o;
+        }
+        __syncthreads();
+        if (tid < (int)world) { uint32_t s2 = 0; for (int w = 0; w < DD_WG / 64; ++w) s2 += wcnt[w][tid]; base[tid] += s2; }
+        __syncthreads();
+    }
+}
+__global__ void k_unpermute_flags(const uint8_t* in, const uint32_t* perm, uint64_t n, uint8_t* out, unsigned long long* dups) {
+    uint32_t mine = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint8_t f = in[perm[j]];
+        out[j] = f;
+        mine += f ? 1u : 0u;
+    }
+    if (mine) atomicAdd(dups, (unsigned long long)mine);
+}
+size_t partition_work_bytes() { return (size_t)(kMaxWorld * 1024 + 64) * 4; }
+// hist: kMaxWorld x G counters (device work buffer); after the call hist[d * G] is where destination d starts in `send`
+hipError_t launch_partition(const KeyRec* keys, uint64_t n, const uint16_t* d_lut, uint32_t world, uint32_t* hist, KeyRec* send, uint32_t* perm, uint32_t* G_out, hipStream_t s) {
+    if (world == 0 || world > kMaxWorld || n >= (1ull << 32)) return hipErrorInvalidValue;
+    uint32_t G = (uint32_t)((n + 8191) / 8192);
+    if (G > 1024) G = 1024;
+    if (G == 0) G = 1;
+    *G_out = G;
+    const uint64_t per = (n + G - 1) / G;
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)kMaxWorld * G * 4, s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(k_part_hist, dim3(G), dim3(DD_WG), 0, s, keys, n, per, d_lut, world, hist, G);
+    hipLaunchKernelGGL(k_dd_scan, dim3(1), dim3(NT), 0, s, hist, kMaxWorld * G);
+    hipLaunchKernelGGL(k_part_scatter, dim3(G), dim3(DD_WG), 0, s, keys, n, per, d_lut, world, (const uint32_t*)hist, G, send, perm);
+    return hipGetLastError();
+}
+hipError_t launch_unpermute(const uint8_t* in, const uint32_t* perm, uint64_t n, uint8_t* out, unsigned long long* dups, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(dups, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess || n == 0) return e;
+    hipLaunchKernelGGL(k_unpermute_flags, dim3(1024), dim3(256), 0, s, in, perm, n, out, dups);
     return hipGetLastError();
 }
 

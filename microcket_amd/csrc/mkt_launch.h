@@ -69,6 +69,9 @@ hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_grou
 struct DedupResult { uint64_t total, dups; };
 hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* work, size_t work_bytes, DedupResult* d_res, hipStream_t s);
 size_t dedup_work_bytes(uint64_t n);
+size_t partition_work_bytes();
+hipError_t launch_partition(const KeyRec* keys, uint64_t n, const uint16_t* d_lut, uint32_t world, uint32_t* hist, KeyRec* send, uint32_t* perm, uint32_t* G_out, hipStream_t s);
+hipError_t launch_unpermute(const uint8_t* in, const uint32_t* perm, uint64_t n, uint8_t* out, unsigned long long* dups, hipStream_t s);
 hipError_t launch_chrstat(const KeyRec* keys, uint64_t n, const uint16_t* dense_of_slot, uint32_t ndense, unsigned long long* counts, hipStream_t s);
 
 hipError_t launch_synth_sizes(const SynParams& p, uint64_t first, uint64_t n, uint64_t* sizes, hipStream_t s);

@@ -17,7 +17,7 @@ t = ctx.timing()
 print("stop=%%s kernel_ms_per_pass %%.3f  GB/s %%.1f" %% (os.environ.get("MKT_DEBUG_STOP","0"), t.tile_kernel_ms, ds.total_bytes / t.tile_kernel_ms / 1e6))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = sys.argv[1] if len(sys.argv) > 1 else "libmkt_hip_stamps.so"
-stops = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 3, 4, 6, 7, 0)
+stops = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else (1, 2, 9, 3, 4, 6, 7, 0)
 print("lib", lib, flush=True)
 for k in stops:
     env = dict(os.environ, MKT_DEBUG_STOP=str(k), MKT_NO_STAMPS="1", MKT_LIB=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "microcket_amd", lib))

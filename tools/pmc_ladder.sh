@@ -15,6 +15,6 @@ for _ in range(2):
     except Exception: pass
 PY
 cd /tmp
-for k in 1 2 3 4 6 7 0; do
+for k in 1 2 9 3 4 6 7 0; do
   MKT_DEBUG_STOP=$k MKT_NO_STAMPS=1 MKT_LIB=$R/microcket_amd/libmkt_hip_stamps.so rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/$OUT/stop$k -- python3 /tmp/pl_run.py > /dev/null 2> $R/$OUT/stop$k.err
 done
