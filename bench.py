@@ -199,6 +199,7 @@ def main():
             torch = None
 
     import microcket_amd as m
+    from microcket_amd import shard
 
     def barrier():
         if dist is not None:
@@ -216,6 +217,7 @@ def main():
                      tail_group=(rank == world - 1))
     log(f"[rank {rank}] data set: {ds.total_groups} pairs, {ds.total_bytes / 1e9:.2f} GB in {ds.n_blocks} blocks, generated in {time.time() - t0:.1f} s")
     drop_last = rank == world - 1          # every rank holds pairs; the input's end is on the last one (quirk Q1)
+    global_dedup = dedup and dist is not None and args.backend == "nccl"
     ext_out = {}
 
     def run_steps(c, steps, with_dedup):
@@ -227,7 +229,14 @@ def main():
             for (p, n, _g) in ds.blocks:
                 c.submit_device(p, n)
             if with_dedup:
-                tot, dups, _ = c.ext_dedup(drop_last, want_flags=False)
+                if global_dedup:
+                    # N > 1: the key space is hash-partitioned across the ranks (all_to_all over RCCL / xGMI, device buffers),
+                    # marked where the equal keys meet, flags returned: duplicates are found across shards, inside the step
+                    _f, dups, dups_all = shard.dedup_exchange(c, rank, world, drop_last, dist, torch, torch.device("cuda", local), want_flags=False)
+                    tot = c.ext_key_count(drop_last)
+                    ext_out.update(duplicates_all_ranks=dups_all)
+                else:
+                    tot, dups, _ = c.ext_dedup(drop_last, want_flags=False)
                 rows = c.ext_chrstat(drop_last)
                 ext_out.update(reported_pairs=tot, duplicates=dups, chrstat_rows=len(rows.splitlines()))
         c.sync()
@@ -358,7 +367,8 @@ def main():
             "counters": dict(zip(["lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0", "pairs", "pair_bytes", "duplicates"], counters)),
         }
         if dedup:
-            result["dedup"] = dict(ext_out, scope="per GPU shard (cross-shard reconciliation: microcket_amd.shard.dedup_sharded, not part of the step)",
+            result["dedup"] = dict(ext_out, scope=("global: hash-partitioned all_to_all of the key space over RCCL inside every step (microcket_amd.shard.dedup_exchange)"
+                                                   if global_dedup else "one GPU holds the whole input" if world == 1 else "per GPU shard (gloo rehearsal)"),
                                    note="extension, not in the reference's sam2pairs: default off in the library, never changes stdout/.sam/.log")
             el2, ms2, ln2 = plain
             ach2 = (algo_bytes_step * args.steps) / (ms2 / 1e3) / 1e9 if ms2 > 0 else 0.0

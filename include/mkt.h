@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 5
+#define MKT_ABI_VERSION 6
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -65,7 +65,9 @@ typedef struct mkt_params {
  * src/preprocess/krmdup.cpp:151-213): default off, they never change stdout / .sam / .log, parity is unpinned.
  * MKT_EXT_KEYS makes the kernels also emit one key record per reported pair (chr1,pos1,chr2,pos2,strand1,strand2),
  * kept on the device in input order; mkt_ext_dedup / mkt_ext_chrstat work on those after the end of the input. */
-enum { MKT_EXT_KEYS = 1 };
+enum { MKT_EXT_KEYS = 1,
+       MKT_EXT_LANES = 2 };    /* with MKT_EXT_KEYS: the read's sequencing lane (QNAME field 4) is part of the duplicate key, i.e. duplicates
+                                * never span lanes -- the driver's -b, which runs one krmdup per lane (microcket:421-451) */
 
 /* The 8 counters of <prefix>.<mode>2pairs.log in file order (sam2pairs.cpp:211-218), plus totals. */
 typedef struct mkt_stats {
@@ -189,6 +191,20 @@ int mkt_ext_dedup(mkt_ctx* ctx, int drop_last, uint64_t* total, uint64_t* dups, 
 int mkt_ext_chr_names(mkt_ctx* ctx, char* out, size_t cap, size_t* len);
 int mkt_ext_keys_fetch(mkt_ctx* ctx, int drop_last, void* keys, size_t cap_bytes, uint64_t* n);
 int mkt_ext_dedup_keys(mkt_ctx* ctx, const void* keys, uint64_t n, uint8_t* flags, uint64_t* dups);
+/* The same for sharded runs as an xGMI design: every key record travels to rank mix64(key) % world, so equal keys meet on
+ * one GPU (microcket_amd/shard.py: dedup_exchange drives it with three all_to_all_single calls on DEVICE buffers over RCCL).
+ *   mkt_ext_keys_device   the context's key list where it lies in HBM (input order);
+ *   mkt_ext_partition     rewrites chromosome slots through lut (8192 entries, host; from the exchanged name tables; NULL:
+ *                         keep) and writes the records grouped by destination rank, in input order inside every group, to the
+ *                         device buffer d_send (24 bytes per record); counts[r] = records for rank r (world <= 16);
+ *   mkt_ext_dedup_device  duplicate flags (device, one byte per record) for n key records lying in device memory, first
+ *                         in buffer order wins;
+ *   mkt_ext_unpartition   flags that came back in d_send order -> the context's input order (host buffer `flags`, may be
+ *                         NULL); *dups = duplicates among this context's pairs. */
+int mkt_ext_keys_device(mkt_ctx* ctx, int drop_last, const void** d_keys, uint64_t* n);
+int mkt_ext_partition(mkt_ctx* ctx, int drop_last, const uint16_t* lut, uint32_t world, void* d_send, uint64_t* counts);
+int mkt_ext_dedup_device(mkt_ctx* ctx, const void* d_keys, uint64_t n, uint8_t* d_flags, uint64_t* dups);
+int mkt_ext_unpartition(mkt_ctx* ctx, const uint8_t* d_flags_part, uint8_t* flags, size_t flags_cap, uint64_t* dups);
 
 /* Per-chromosome contact counts of the reported pairs: lines "chrA\tchrB\tcount\n" sorted bytewise by (chrA, chrB). */
 int mkt_ext_chrstat(mkt_ctx* ctx, int drop_last, char* out, size_t cap, size_t* len);

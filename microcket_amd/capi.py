@@ -7,12 +7,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_FLASH, MODE_UNC = 0, 1
 TILES_AUTO, TILES_FAST, TILES_SMALL = 0, 1, 2
 EXT_KEYS = 1
+EXT_LANES = 2
+KEY_BYTES = 24
 EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
     "mkt_input_window", "mkt_submit_window",
     "mkt_submit", "mkt_drain", "mkt_drain_wait", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
-    "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
+    "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
 ]
 
 
@@ -99,6 +101,10 @@ def load_library():
     L.mkt_ext_keys_fetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     L.mkt_ext_dedup_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.mkt_group_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mkt_ext_keys_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.mkt_ext_partition.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mkt_ext_dedup_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
+    L.mkt_ext_unpartition.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -276,6 +282,41 @@ class Context:
         if n:
             self._chk(self.L.mkt_ext_dedup_keys(self.h, keys.ctypes.data_as(C.c_void_p), n, flags.ctypes.data_as(C.c_void_p), C.byref(dups)), "mkt_ext_dedup_keys")
         return flags, dups.value
+
+    # ---- sharded duplicate marking: the device side of microcket_amd.shard.dedup_exchange (torch tensors carry the buffers)
+    def ext_key_count(self, drop_last=True):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.mkt_ext_keys_device(self.h, 1 if drop_last else 0, C.byref(p), C.byref(n)), "mkt_ext_keys_device")
+        return n.value
+
+    def ext_partition(self, drop_last, lut, world, torch, device):
+        """Key records grouped by destination rank (stable) in a uint8 device tensor of 24 n bytes; returns (tensor, counts)."""
+        import numpy as np
+        n = self.ext_key_count(drop_last)
+        send = torch.empty(max(n, 1) * KEY_BYTES, dtype=torch.uint8, device=device)
+        counts = (C.c_uint64 * 16)()
+        lut = None if lut is None else np.ascontiguousarray(lut, dtype=np.uint16)
+        assert lut is None or lut.shape[0] == 8192
+        self._chk(self.L.mkt_ext_partition(self.h, 1 if drop_last else 0, None if lut is None else lut.ctypes.data_as(C.c_void_p), world,
+                                           C.c_void_p(send.data_ptr()), counts), "mkt_ext_partition")
+        return send[:n * KEY_BYTES], [int(counts[r]) for r in range(world)]
+
+    def ext_dedup_tensor(self, recv, torch):
+        """Duplicate flags (uint8 device tensor) for the key records lying in the uint8 device tensor recv, first in buffer order wins."""
+        n = recv.numel() // KEY_BYTES
+        flags = torch.zeros(max(n, 1), dtype=torch.uint8, device=recv.device)
+        dups = C.c_uint64()
+        if n:
+            self._chk(self.L.mkt_ext_dedup_device(self.h, C.c_void_p(recv.data_ptr()), n, C.c_void_p(flags.data_ptr()), C.byref(dups)), "mkt_ext_dedup_device")
+        return flags[:n], dups.value
+
+    def ext_unpartition(self, flags_part, want_flags=True):
+        """Flags that came back in ext_partition's order -> input order (bytes) and the number of duplicates among this context's pairs."""
+        n = flags_part.numel()
+        dups = C.c_uint64()
+        buf = C.create_string_buffer(max(n, 1)) if want_flags else None
+        self._chk(self.L.mkt_ext_unpartition(self.h, C.c_void_p(flags_part.data_ptr()) if n else None, buf, n if want_flags else 0, C.byref(dups)), "mkt_ext_unpartition")
+        return (buf.raw[:n] if want_flags else b""), dups.value
 
     def ext_chrstat(self, drop_last=True):
         n = C.c_size_t()

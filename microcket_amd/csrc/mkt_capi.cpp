@@ -44,6 +44,7 @@ struct mkt_ctx {
     uint8_t* h_chr_stage = nullptr; uint16_t* d_dense = nullptr;              // mkt_ext_chrstat: pinned staging, slot -> dense id
     uint8_t* d_dd_flags = nullptr; size_t dd_flags_cap = 0; void* d_dd_work = nullptr; size_t dd_work_cap = 0;      // mkt_ext_dedup
     DedupResult* d_dd_res = nullptr; DedupResult* h_dd_res = nullptr;
+    uint32_t* d_perm = nullptr; size_t perm_cap = 0; uint32_t* d_part_hist = nullptr; uint16_t* d_lut = nullptr; uint64_t part_n = 0;      // sharded duplicate marking
     unsigned long long* d_chr_counts = nullptr; unsigned long long* h_chr_counts = nullptr; size_t chr_counts_cap = 0;
     double sc_density = 0;                                // most self-circles per input byte seen between two syncs (0: nothing seen yet)
     uint64_t* d_sc_tmp = nullptr; size_t sc_tmp_cap = 0;  // per block: raw (tile, ordinal) entries, one slice per region
@@ -252,6 +253,9 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_dd_flags) (void)hipFree(c->d_dd_flags);
     if (c->d_dd_work) (void)hipFree(c->d_dd_work);
     if (c->d_dd_res) (void)hipFree(c->d_dd_res);
+    if (c->d_perm) (void)hipFree(c->d_perm);
+    if (c->d_part_hist) (void)hipFree(c->d_part_hist);
+    if (c->d_lut) (void)hipFree(c->d_lut);
     if (c->h_dd_res) (void)hipHostFree(c->h_dd_res);
     if (c->d_dense) (void)hipFree(c->d_dense);
     if (c->d_chr_counts) (void)hipFree(c->d_chr_counts);
@@ -355,6 +359,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
         }
         a.keys_rcap = c->keys_raw_cap / a.nregions;
         a.out.keys = c->d_keys_raw; a.out.keys_cap = c->keys_raw_cap; a.out.chr = c->d_chr;
+        a.out.key_lanes = (c->p.extensions & MKT_EXT_LANES) ? 1u : 0u;
         a.key_list = c->d_key_list; a.key_list_cap = c->key_list_cap;
     }
 #if defined(MKT_STAMPS)
@@ -973,6 +978,7 @@ static uint64_t ext_key_count(mkt_ctx* c, int drop_last) {
     if (drop_last && c->acc.pending.valid && c->acc.pending.pair_bytes && n) --n;     // quirk Q1: the input's last group reported a pair
     return n;
 }
+static int ensure_dedup_work(mkt_ctx* c, uint64_t n);
 int mkt_ext_dedup(mkt_ctx* c, int drop_last, uint64_t* total, uint64_t* dups, uint8_t* flags, size_t flags_cap) {
     if (!c) return MKT_E_ARG;
     if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
@@ -983,24 +989,8 @@ int mkt_ext_dedup(mkt_ctx* c, int drop_last, uint64_t* total, uint64_t* dups, ui
     if (dups) *dups = 0;
     if (n == 0) return MKT_OK;
     if (flags && flags_cap < n) return fail(c, MKT_E_ARG, "flags buffer too small (%llu needed)", (unsigned long long)n);
-    // work buffers are kept between calls (GB-sized hipMalloc / hipFree pairs cost more than the marking itself)
     const size_t wb = dedup_work_bytes(n);
-    if (c->dd_flags_cap < n) {
-        if (c->d_dd_flags) HIPCHK(c, hipFree(c->d_dd_flags));
-        c->d_dd_flags = nullptr; c->dd_flags_cap = 0;
-        HIPCHK(c, hipMalloc((void**)&c->d_dd_flags, n + n / 8 + 4096));
-        c->dd_flags_cap = n + n / 8 + 4096;
-    }
-    if (c->dd_work_cap < wb) {
-        if (c->d_dd_work) HIPCHK(c, hipFree(c->d_dd_work));
-        c->d_dd_work = nullptr; c->dd_work_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_dd_work, wb + wb / 8));
-        c->dd_work_cap = wb + wb / 8;
-    }
-    if (!c->d_dd_res) {
-        HIPCHK(c, hipMalloc((void**)&c->d_dd_res, sizeof(DedupResult)));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_dd_res, sizeof(DedupResult), hipHostMallocDefault));
-    }
+    if ((rc = ensure_dedup_work(c, n))) return rc;
     HIPCHK(c, launch_dedup(c->d_key_list, n, c->d_dd_flags, c->d_dd_work, wb, c->d_dd_res, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_dd_res, c->d_dd_res, sizeof(DedupResult), hipMemcpyDeviceToHost, c->stream));
     if (flags) HIPCHK(c, hipMemcpyAsync(flags, c->d_dd_flags, n, hipMemcpyDeviceToHost, c->stream));
@@ -1041,25 +1031,115 @@ int mkt_ext_keys_fetch(mkt_ctx* c, int drop_last, void* keys, size_t cap_bytes, 
     }
     return MKT_OK;
 }
+// work buffers of the duplicate marking, kept between calls (GB-sized hipMalloc / hipFree pairs cost more than the marking)
+static int ensure_dedup_work(mkt_ctx* c, uint64_t n) {
+    const size_t wb = dedup_work_bytes(n);
+    if (c->dd_flags_cap < n) {
+        if (c->d_dd_flags) HIPCHK(c, hipFree(c->d_dd_flags));
+        c->d_dd_flags = nullptr; c->dd_flags_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_dd_flags, n + n / 8 + 4096));
+        c->dd_flags_cap = n + n / 8 + 4096;
+    }
+    if (c->dd_work_cap < wb) {
+        if (c->d_dd_work) HIPCHK(c, hipFree(c->d_dd_work));
+        c->d_dd_work = nullptr; c->dd_work_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_dd_work, wb + wb / 8));
+        c->dd_work_cap = wb + wb / 8;
+    }
+    if (!c->d_dd_res) {
+        HIPCHK(c, hipMalloc((void**)&c->d_dd_res, sizeof(DedupResult)));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_dd_res, sizeof(DedupResult), hipHostMallocDefault));
+    }
+    return MKT_OK;
+}
+int mkt_ext_dedup_device(mkt_ctx* c, const void* d_keys, uint64_t n, uint8_t* d_flags, uint64_t* dups) {
+    if (!c || (n && (!d_keys || !d_flags))) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    if (dups) *dups = 0;
+    if (n == 0) return MKT_OK;
+    int rc = ensure_dedup_work(c, n);
+    if (rc) return rc;
+    HIPCHK(c, launch_dedup((const KeyRec*)d_keys, n, d_flags, c->d_dd_work, dedup_work_bytes(n), c->d_dd_res, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_dd_res, c->d_dd_res, sizeof(DedupResult), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dups) *dups = c->h_dd_res->dups;
+    return MKT_OK;
+}
 int mkt_ext_dedup_keys(mkt_ctx* c, const void* keys, uint64_t n, uint8_t* flags, uint64_t* dups) {
     if (!c || (n && (!keys || !flags))) return MKT_E_ARG;
     HIPCHK(c, hipSetDevice(c->p.device));
     if (dups) *dups = 0;
     if (n == 0) return MKT_OK;
-    KeyRec* d_keys = nullptr; uint8_t* d_flags = nullptr; void* d_work = nullptr; DedupResult* d_res = nullptr;
-    const size_t wb = dedup_work_bytes(n);
+    int rc = ensure_dedup_work(c, n);
+    if (rc) return rc;
+    KeyRec* d_keys = nullptr;
     HIPCHK(c, hipMalloc((void**)&d_keys, (size_t)n * sizeof(KeyRec)));
-    HIPCHK(c, hipMalloc((void**)&d_flags, n));
-    HIPCHK(c, hipMalloc(&d_work, wb));
-    HIPCHK(c, hipMalloc((void**)&d_res, sizeof(DedupResult)));
-    HIPCHK(c, hipMemcpyAsync(d_keys, keys, (size_t)n * sizeof(KeyRec), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_dedup(d_keys, n, d_flags, d_work, wb, d_res, c->stream));
-    DedupResult r;
-    HIPCHK(c, hipMemcpyAsync(&r, d_res, sizeof r, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, c->stream));
+    hipError_t e = hipMemcpyAsync(d_keys, keys, (size_t)n * sizeof(KeyRec), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_dedup(d_keys, n, c->d_dd_flags, c->d_dd_work, dedup_work_bytes(n), c->d_dd_res, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_dd_res, c->d_dd_res, sizeof(DedupResult), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(flags, c->d_dd_flags, n, hipMemcpyDeviceToHost, c->stream);
+    const hipError_t e2 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_keys);                                   // on every path
+    if (e != hipSuccess || e2 != hipSuccess) return fail(c, MKT_E_HIP, "duplicate marking of %llu host keys failed: %s", (unsigned long long)n, hipGetErrorString(e != hipSuccess ? e : e2));
+    if (dups) *dups = c->h_dd_res->dups;
+    return MKT_OK;
+}
+int mkt_ext_keys_device(mkt_ctx* c, int drop_last, const void** d_keys, uint64_t* n) {
+    if (!c || !d_keys || !n) return MKT_E_ARG;
+    if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    *n = ext_key_count(c, drop_last);
+    *d_keys = c->d_key_list;
+    return MKT_OK;
+}
+int mkt_ext_partition(mkt_ctx* c, int drop_last, const uint16_t* lut, uint32_t world, void* d_send, uint64_t* counts) {
+    if (!c || !counts || world == 0 || world > 16) return MKT_E_ARG;
+    if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");
+    int rc = mkt_sync(c);
+    if (rc) return rc;
+    const uint64_t n = ext_key_count(c, drop_last);
+    for (uint32_t d = 0; d < world; ++d) counts[d] = 0;
+    c->part_n = n;
+    if (n == 0) return MKT_OK;
+    if (!d_send) return MKT_E_ARG;
+    if (c->perm_cap < n) {
+        if (c->d_perm) HIPCHK(c, hipFree(c->d_perm));
+        c->d_perm = nullptr; c->perm_cap = 0;
+        HIPCHK(c, hipMalloc((void**)&c->d_perm, (n + n / 8 + 1024) * sizeof(uint32_t)));
+        c->perm_cap = n + n / 8 + 1024;
+    }
+    if (!c->d_part_hist) HIPCHK(c, hipMalloc((void**)&c->d_part_hist, partition_work_bytes()));
+    if (lut) {
+        if (!c->d_lut) HIPCHK(c, hipMalloc((void**)&c->d_lut, kChrSlots * sizeof(uint16_t)));
+        HIPCHK(c, hipMemcpyAsync(c->d_lut, lut, kChrSlots * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+    }
+    uint32_t G = 1;
+    HIPCHK(c, launch_partition(c->d_key_list, n, lut ? c->d_lut : nullptr, world, c->d_part_hist, (KeyRec*)d_send, c->d_perm, &G, c->stream));
+    std::vector<uint32_t> hh((size_t)16 * G);
+    HIPCHK(c, hipMemcpyAsync(hh.data(), c->d_part_hist, hh.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    (void)hipFree(d_keys); (void)hipFree(d_flags); (void)hipFree(d_work); (void)hipFree(d_res);
-    if (dups) *dups = r.dups;
+    for (uint32_t d = 0; d < world; ++d) {
+        const uint64_t lo = hh[(size_t)d * G], hi = d + 1 < 16 ? hh[(size_t)(d + 1) * G] : n;      // starts of the destinations in `send` (exclusive scan)
+        counts[d] = (d + 1 < world ? hi : n) - lo;
+    }
+    return MKT_OK;
+}
+int mkt_ext_unpartition(mkt_ctx* c, const uint8_t* d_flags_part, uint8_t* flags, size_t flags_cap, uint64_t* dups) {
+    if (!c) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    const uint64_t n = c->part_n;
+    if (dups) *dups = 0;
+    if (n == 0) return MKT_OK;
+    if (!d_flags_part || !c->d_perm) return MKT_E_ARG;
+    if (flags && flags_cap < n) return fail(c, MKT_E_ARG, "flags buffer too small (%llu needed)", (unsigned long long)n);
+    int rc = ensure_dedup_work(c, n);
+    if (rc) return rc;
+    HIPCHK(c, launch_unpermute(d_flags_part, c->d_perm, n, c->d_dd_flags, (unsigned long long*)&c->d_dd_res->dups, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_dd_res, c->d_dd_res, sizeof(DedupResult), hipMemcpyDeviceToHost, c->stream));
+    if (flags) HIPCHK(c, hipMemcpyAsync(flags, c->d_dd_flags, n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (dups) *dups = c->h_dd_res->dups;
     return MKT_OK;
 }
 int mkt_ext_chrstat(mkt_ctx* c, int drop_last, char* out, size_t cap, size_t* len) {

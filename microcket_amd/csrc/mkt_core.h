@@ -642,7 +642,7 @@ MKT_HD uint8_t pair_line_byte(const TextView& tv, uint32_t qn_abs, uint32_t qn_l
 // chromosome NAMES replaced by their slot in the run's name table (64-bit FNV-1a keyed, see chr_slot).
 struct KeyRec {
     uint64_t k0;       // chrA slot << 45 | chrB slot << 32 | posA
-    uint64_t k1;       // posB << 32 | sA('-') << 31 | sB('-') << 30
+    uint64_t k1;       // posB << 32 | sA('-') << 31 | sB('-') << 30 | lane (16 bits; MKT_EXT_LANES only)
     uint64_t ord;      // raw: tile << 16 | emit ordinal in tile ; placed: emitted-pair ordinal in input order
 };
 constexpr uint32_t kChrSlots = 8192;               // open addressing, power of two

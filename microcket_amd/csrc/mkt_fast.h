@@ -427,7 +427,8 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
             uint32_t err = 0;
             const uint32_t sa = fast_chr_slot(st, out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
             const uint32_t sb = fast_chr_slot(st, out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
-            out.keys[k] = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i]);
+            const uint32_t lane = out.key_lanes ? qname_lane(tv, (uint32_t)st.off16[i] + st.qn_off[i], st.qn_len[i]) : 0u;
+            out.keys[k] = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i], lane);
             if (err) lds_or(&st.abn, err << 8);
         } else lds_or(&st.abn, E_SC_CAP << 8);
     }

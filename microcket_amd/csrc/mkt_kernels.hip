@@ -426,6 +426,31 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
     if (tid0 < (int)C_COUNT) wg_cnt[tid0] = 0;
     fast_init(st, (uint32_t)tid0);
     // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
+#if defined(MKT_STAGGER_SHIFT)
+    // Workgroups of one launch all start in the same phase and, tile after tile of equal work, stay there: everybody scans
+    // (HBM-bound), then everybody computes.  A one-off delay of part of the workgroups puts them out of phase, so that the scan
+    // of one half meets the compute phases of the other for the rest of the launch.
+    {
+        const uint32_t ph = (blockIdx.x >> MKT_STAGGER_SHIFT) & (uint32_t)(MKT_STAGGER_PHASES - 1);
+        for (uint32_t k = 0; k < ph * (uint32_t)MKT_STAGGER_SLEEPS; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+#ifndef MKT_PREFETCH
+#define MKT_PREFETCH 0       // 16-byte vectors per lane of the NEXT tile's window that are loaded before the current tile's emit phase
+#endif
+    constexpr int PF = MKT_PREFETCH;
+    uint4 xp[PF > 0 ? PF : 1];
+    auto prefetch = [&](uint32_t tt) {       // issue the loads only: they complete behind the latency-bound tail of the current tile
+        const TileGeom Gp = fast_geom<Cfg>(tt, n);
+        const uint32_t nvp = (Gp.w1 - Gp.w0 + 15u) >> 4;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const uint32_t v = (uint32_t)tid0 + (uint32_t)k * NT;
+            xp[k] = make_uint4(0, 0, 0, 0);
+            if (v < nvp) xp[k] = *reinterpret_cast<const uint4*>(a.text + Gp.w0 + (v << 4));
+        }
+    };
+    if (PF > 0 && blockIdx.x < a.ntiles) prefetch(blockIdx.x);
     uint32_t rot = 0;
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         int tid = tid0;
@@ -453,6 +478,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
                     const uint32_t v = tid + (k0 + k) * NT;
                     x[k] = make_uint4(0, 0, 0, 0);
+                    if (k0 + k < PF) { x[k] = xp[k0 + k]; continue; }      // came over during the previous tile's tail
                     // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
                     if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
@@ -637,6 +663,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         __syncthreads();
         STAMP(6);
         STOP_AFTER(6)
+        if (PF > 0 && t + gridDim.x < a.ntiles) prefetch(t + gridDim.x);
         if (st.abn) {                                         // leave the whole tile to the generic kernel
             if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
             __syncthreads();

@@ -470,10 +470,26 @@ MKT_HD uint32_t chr_slot_h(ChrTab* tab, const TextView& tv, uint32_t off, uint32
 MKT_HD uint32_t chr_slot(ChrTab* tab, const TextView& tv, uint32_t off, uint32_t len, uint32_t* err) {
     return chr_slot_h(tab, tv, off, len, fnv1a64(tv, off, len), err);
 }
-MKT_HD KeyRec make_key(uint32_t slotA, uint32_t posA, uint32_t slotB, uint32_t posB, bool minusA, bool minusB, uint32_t tile, uint32_t ordinal) {
+// The sequencing lane of a read: the fourth ':'-separated field of an Illumina-style QNAME (instrument:run:flowcell:LANE:tile:x:y),
+// decimal; 0 when the name has no such field.  With MKT_EXT_LANES it joins the duplicate-marking key, which is the driver's
+// -b ("inter-lane duplicates are kept": it runs one krmdup per lane, microcket:421-451).
+MKT_HD uint32_t qname_lane(const TextView& tv, uint32_t off, uint32_t len) {
+    uint32_t colons = 0, p = 0;
+    while (p < len && colons < 3u) { if (tv.at(off + p) == ':') ++colons; ++p; }
+    if (colons < 3u) return 0u;
+    uint32_t v = 0, nd = 0;
+    while (p < len) {
+        const uint32_t d = (uint32_t)tv.at(off + p) - (uint32_t)'0';
+        if (d > 9u) break;
+        v = v * 10u + d; ++nd; ++p;
+        if (v > 0xFFFFu) return 0xFFFFu;
+    }
+    return nd ? v : 0u;
+}
+MKT_HD KeyRec make_key(uint32_t slotA, uint32_t posA, uint32_t slotB, uint32_t posB, bool minusA, bool minusB, uint32_t tile, uint32_t ordinal, uint32_t lane = 0) {
     KeyRec k;
     k.k0 = ((uint64_t)slotA << 45) | ((uint64_t)slotB << 32) | posA;
-    k.k1 = ((uint64_t)posB << 32) | ((uint64_t)(minusA ? 1u : 0u) << 31) | ((uint64_t)(minusB ? 1u : 0u) << 30);
+    k.k1 = ((uint64_t)posB << 32) | ((uint64_t)(minusA ? 1u : 0u) << 31) | ((uint64_t)(minusB ? 1u : 0u) << 30) | (uint64_t)(lane & 0xFFFFu);
     k.ord = ((uint64_t)tile << 16) | ordinal;
     return k;
 }
@@ -484,6 +500,7 @@ struct OutPtrs {                        // *_cap: end of the range this tile may
     uint64_t* sc; uint64_t sc_cap;      // self-circle groups: (tile << 32 | ordinal in tile), resolved to global indices by k_finish
     KeyRec* keys; uint64_t keys_cap;    // extension: raw key records of the block (null: extension off)
     ChrTab* chr;
+    uint32_t key_lanes, pad_;           // extension MKT_EXT_LANES: the read's lane (QNAME field 4) is part of the key
 };
 
 // slow .sam copy: surviving lines of [first line, last member end), each followed by '\n'
@@ -519,7 +536,8 @@ template <class Cfg> MKT_HD void ph_account(TileState<Cfg>& st, const TextView& 
         if (k < out.keys_cap) {
             const uint32_t sa = chr_slot(out.chr, tv, g.g_chrA[i], g.g_chrA_len[i], &st.err);
             const uint32_t sb = chr_slot(out.chr, tv, g.g_chrB[i], g.g_chrB_len[i], &st.err);
-            out.keys[k] = make_key(sa, g.g_posA[i], sb, g.g_posB[i], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i]);
+            const uint32_t lane = out.key_lanes ? qname_lane(tv, st.off[i] + st.qn_off[i], st.qn_len[i]) : 0u;
+            out.keys[k] = make_key(sa, g.g_posA[i], sb, g.g_posB[i], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i], lane);
         } else lds_or(&st.err, E_SC_CAP);
     }
     if ((info & GI_EMIT) && P.write_sam && !(info & GI_CONTIG)) sam_copy_slow(st, tv, P, out, i);

@@ -134,6 +134,49 @@ def dedup_sharded(ctx, rank, world, drop_last, all_gather_obj, all_gather_keys):
     return mine, int(mine.sum()), int(total_dups)
 
 
+def dedup_exchange(engine, rank, world, drop_last, dist, torch, device, want_flags=True):
+    """Pairs-level duplicate marking across shards as an xGMI design (extension): the key space is
+    hash-partitioned, not gathered.  Every key record travels to rank mix64(key) % world in ONE all_to_all_single of device
+    buffers (RCCL over xGMI: each GPU sends 1/world of its keys over each link, nothing goes through the host), is marked
+    there together with the equal keys of all other ranks, and one byte per record travels back the same way.
+
+    "First in input order wins" survives the exchange because shards are contiguous ranges of the input in rank order:
+    the partition is stable, all_to_all delivers the segments in source-rank order, so every rank marks its share in
+    global input order.  Chromosome slots are per context: the (tiny) name tables are gathered first and every slot is
+    rewritten to the rank of its name in the sorted union.
+
+    engine: microcket_amd.Context (device kernels) or anything with ext_chr_names / ext_partition / ext_dedup_tensor /
+    ext_unpartition (the CPU stand-in of tests/test_dist.py).  dist: torch.distributed (nccl on GPUs, gloo in the CPU tests).
+    Returns (flags of this rank's reported pairs in input order, duplicates among them, duplicates of the whole run)."""
+    import numpy as np
+    names = engine.ext_chr_names()
+    tables = [None] * world
+    dist.all_gather_object(tables, names)
+    union = sorted(set().union(*[set(t.values()) for t in tables]))
+    gid = {nm: i for i, nm in enumerate(union)}
+    lut = np.zeros(8192, dtype=np.uint16)
+    for slot, nm in names.items():
+        lut[slot] = gid[nm]
+    send, counts = engine.ext_partition(drop_last, lut, world, torch, device)
+    cs = torch.tensor(counts, dtype=torch.int64, device=device)
+    cr = torch.empty_like(cs)
+    dist.all_to_all_single(cr, cs)
+    rcounts = [int(x) for x in cr.tolist()]
+    recv = torch.empty(sum(rcounts) * 24, dtype=torch.uint8, device=device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[c * 24 for c in rcounts], input_split_sizes=[c * 24 for c in counts])
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+    flags_recv, _ = engine.ext_dedup_tensor(recv, torch)
+    back = torch.empty(sum(counts), dtype=torch.uint8, device=device)
+    dist.all_to_all_single(back, flags_recv, output_split_sizes=counts, input_split_sizes=rcounts)
+    if str(device).startswith("cuda"):
+        torch.cuda.synchronize()
+    mine, dups = engine.ext_unpartition(back, want_flags)
+    tot = torch.tensor([dups], dtype=torch.int64, device=device)
+    dist.all_reduce(tot)
+    return mine, int(dups), int(tot.item())
+
+
 def torch_gatherers(dist, torch, device, world):
     """(all_gather_obj, all_gather_keys) over torch.distributed for dedup_sharded: the key arrays travel as padded int64
     tensors on `device` (backend nccl = RCCL over xGMI when device is a GPU; gloo with device "cpu" in the CPU tests)."""

@@ -107,3 +107,49 @@ def test_key_space_gatherers_over_gloo(tmp_path):
     """The exchange primitives of the sharded duplicate marking (shard.torch_gatherers), world_size 2 on CPU."""
     mp.spawn(_gather_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok.0").read_text() == "1" and (tmp_path / "ok.1").read_text() == "1"
+
+
+def _exchange_worker(rank, world, port, path, lanes, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lines = open(path, "rb").read().split(b"\n")[:-1]
+    cuts = [len(lines) * r // world for r in range(world + 1)]
+    if world == 3:
+        cuts[1] = 1                      # a nearly empty shard
+    eng = util.KeyEngine(lines[cuts[rank]:cuts[rank + 1]], rank, lanes)
+    flags, dups, total = shard.dedup_exchange(eng, rank, world, rank == world - 1, dist, torch, "cpu")
+    open(os.path.join(outdir, f"flags.{rank}"), "wb").write(flags)
+    open(os.path.join(outdir, f"tot.{rank}"), "w").write(f"{dups} {total}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("lanes", [False, True])
+def test_hash_partitioned_dedup_exchange_over_gloo(tmp_path, world, lanes):
+    """shard.dedup_exchange (name-table gather, all_to_all of the key space by key hash, flags back, all_reduce) with world_size
+    2 and 3 over gloo; the per-rank engine is a numpy stand-in that uses the same key record layout.  The flags of all
+    ranks, concatenated, must equal the single-stream definition -- also with the lane in the key (the driver's -b)."""
+    text = util.synth("unc", 515, 4000, 100, "mm10", 4)
+    po, so, lo, st = util.oracle_run(text, "unc", 4, 0.5, 10, False)
+    lines = po.split(b"\n")[:-1]
+    # make duplicates: repeat every 5th contact under another read name, in the same lane and in another one
+    extra = []
+    for j, l in enumerate(lines[::5]):
+        f = l.split(b"\t")
+        q = f[0].split(b":")
+        q[-1] = b"9%d" % j
+        extra.append(b"\t".join([b":".join(q)] + f[1:]))
+        q[3] = b"%d" % (int(q[3]) % 4 + 1)
+        extra.append(b"\t".join([b":".join(q)] + f[1:]))
+    allp = b"\n".join(lines + extra) + b"\n"
+    path = tmp_path / "pairs"
+    path.write_bytes(allp)
+    want = util.expected_dups(allp, lanes)
+    assert 0 < sum(want) < len(want)
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(path), lanes, str(tmp_path)), nprocs=world, join=True)
+    got = b"".join((tmp_path / f"flags.{r}").read_bytes() for r in range(world))
+    assert got == want
+    parts = [(tmp_path / f"tot.{r}").read_text().split() for r in range(world)]
+    assert sum(int(p[0]) for p in parts) == sum(want) and all(int(p[1]) == sum(want) for p in parts)

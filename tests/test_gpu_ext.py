@@ -30,8 +30,9 @@ def _expected(pairs_bytes):
     return bytes(flags), txt
 
 
-def _dup_heavy(n_groups):
-    """name-grouped SAM with many exact duplicate contacts (PCR-duplicate like) and chr10/chr2/chrX names"""
+def _dup_heavy(n_groups, lanes=0):
+    """name-grouped SAM with many exact duplicate contacts (PCR-duplicate like) and chr10/chr2/chrX names; lanes > 0: Illumina
+    style read names spread over that many lanes (QNAME field 4)"""
     rows = []
     for g in range(n_groups):
         k = g % 37 if g % 3 else g            # two thirds of the pairs repeat one of 37 contacts
@@ -39,8 +40,9 @@ def _dup_heavy(n_groups):
         c2 = ("chr1", "chr10", "chr2", "chrX")[(k // 4) % 4] if k % 5 == 0 else c1
         p1, p2 = 10000 + 97 * k, 50000 + 131 * k
         f1, f2 = (65, 145) if k % 2 else (81, 129)
-        rows.append(f"r{g}\t{f1}\t{c1}\t{p1}\t60\t50M\t=\t1\t0\t{'ACGT' * 25}\t{'F' * 100}\n")
-        rows.append(f"r{g}\t{f2}\t{c2}\t{p2}\t60\t50M\t=\t1\t0\t{'ACGT' * 25}\t{'F' * 100}\n")
+        q = f"M01:7:FCX:{g * 7 % lanes + 1}:1101:{g}:{3 * g + 1}" if lanes else f"r{g}"
+        rows.append(f"{q}\t{f1}\t{c1}\t{p1}\t60\t50M\t=\t1\t0\t{'ACGT' * 25}\t{'F' * 100}\n")
+        rows.append(f"{q}\t{f2}\t{c2}\t{p2}\t60\t50M\t=\t1\t0\t{'ACGT' * 25}\t{'F' * 100}\n")
     rows.append("zz\t65\tchr1\t1\t60\t50M\t=\t1\t0\tA\tF\nzz\t129\tchr1\t5000\t60\t50M\t=\t1\t0\tA\tF\n")
     return "".join(rows).encode()
 
@@ -127,3 +129,70 @@ def test_sharded_dedup_equals_single_context():
         c.close()
     assert bytes(f0) + bytes(f1) == want
     assert d0 + d1 == dups == tot0 == tot1
+
+
+def test_lane_scoped_duplicates_like_the_drivers_b_switch():
+    """MKT_EXT_LANES: the read's lane (QNAME field 4) joins the key, so equal contacts in different lanes are both kept -- the
+    driver's -b runs one krmdup per lane (microcket:421-451).  Checked against the definition with and without the lane."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    for text in (_dup_heavy(6000, lanes=4), util.synth("unc", 81, 8000, 100, "mm10", 4)):
+        po, so, lo, st = util.oracle_run(text, "unc", 4, 0.5, 10, False)
+        for ext, lanes in ((m.EXT_KEYS, False), (m.EXT_KEYS | m.EXT_LANES, True)):
+            for tiles in (m.TILES_FAST, m.TILES_SMALL):
+                with m.Context("unc", 0.5, 10, False, 4, device=0, block_bytes=1 << 18, tiles=tiles, extensions=ext) as c:
+                    p, s, stats, log = c.run_bytes(text, chunk=1 << 20)
+                    total, dups, flags = c.ext_dedup(True)
+                assert log == lo and util.canon(p) == util.canon(po)
+                assert flags == util.expected_dups(po, lanes), (lanes, tiles)
+    assert util.expected_dups(util.oracle_run(_dup_heavy(6000, lanes=4), "unc", 4, 0.5, 10, False)[0], True) != \
+        util.expected_dups(util.oracle_run(_dup_heavy(6000, lanes=4), "unc", 4, 0.5, 10, False)[0], False)
+
+
+@pytest.mark.parametrize("lanes", [False, True])
+def test_hash_partitioned_exchange_on_device(lanes):
+    """The xGMI design of the sharded duplicate marking with its REAL device side: two contexts = two shards on one GPU, one
+    thread per rank, microcket_amd.shard.dedup_exchange over an in-process stand-in for torch.distributed (the collectives
+    move torch CUDA tensors; bench.py passes torch.distributed with the nccl = RCCL backend).  Partition, remap, marking
+    of the received records and the way back all run as HIP kernels; the flags must equal the single-context result."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    import threading
+    import torch
+    from microcket_amd import shard
+    ext = m.EXT_KEYS | (m.EXT_LANES if lanes else 0)
+    text = _dup_heavy(5000, lanes=4) + util.synth("unc", 71, 3000, 100, "mm10", 4)
+    with m.Context("unc", 0.5, 10, False, 4, device=0, extensions=ext, ordered=True) as c:
+        c.run_bytes(text)
+        total, dups, want = c.ext_dedup(True)
+    po = util.oracle_run(text, "unc", 4, 0.5, 10, False)[0]
+    assert want == util.expected_dups(po, lanes)
+    for world in (2, 3):
+        cuts = shard.cut_points(text, world, min_mapq=10)
+        ctxs = [m.Context("unc", 0.5, 10, False, 4, device=0, extensions=ext) for _ in range(world)]
+        for r in reversed(range(world)):      # the name tables fill in different orders
+            ctxs[r].submit(text[cuts[r]:cuts[r + 1]], last=True)
+        counts = [c.group_count() for c in ctxs]
+        for r, c in enumerate(ctxs):
+            c.finish(drop_last=(r == world - 1), group_offset=sum(counts[:r]), total_groups=sum(counts))
+        fd = util.FakeDist(world)
+        res = [None] * world
+        err = []
+
+        def run(r):
+            try:
+                res[r] = shard.dedup_exchange(ctxs[r], r, world, r == world - 1, fd.rank(r), torch, "cuda:0")
+            except Exception as ex:          # a dead rank must not leave the others at a barrier
+                err.append(ex)
+                fd.bar.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for c in ctxs:
+            c.close()
+        assert not err, err
+        assert b"".join(res[r][0] for r in range(world)) == want
+        assert sum(res[r][1] for r in range(world)) == dups and all(res[r][2] == dups for r in range(world))

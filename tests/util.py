@@ -198,3 +198,141 @@ class EmulShard:
         if self.h:
             _emul.emul_close(self.h)
             self.h = None
+
+
+# ---- sharded duplicate marking: CPU stand-ins for the exchange of microcket_amd.shard.dedup_exchange -----------------------
+def _mix64_np(x):
+    import numpy as np
+    x = x.copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd); x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53); x ^= x >> np.uint64(33)
+    return x
+
+
+def qname_lane(q: bytes) -> int:
+    f = q.split(b":")
+    if len(f) < 4:
+        return 0
+    d = b""
+    for ch in f[3]:
+        if 48 <= ch <= 57:
+            d += bytes([ch])
+        else:
+            break
+    return min(int(d), 0xFFFF) if d else 0
+
+
+def expected_dups(pairs_bytes, lanes=False):
+    """The definition, over .pairs lines in input order: a pair is a duplicate when an EARLIER pair has the same
+    (chr1, pos1, chr2, pos2, strand1, strand2) [and lane, with lanes=True]."""
+    seen = set()
+    flags = bytearray()
+    for line in pairs_bytes.split(b"\n")[:-1]:
+        f = line.split(b"\t")
+        key = tuple(f[1:7]) + ((qname_lane(f[0]),) if lanes else ())
+        flags.append(1 if key in seen else 0)
+        seen.add(key)
+    return bytes(flags)
+
+
+class KeyEngine:
+    """TEST stand-in for microcket_amd.Context in the key exchange: key records built from .pairs lines (numpy), the same
+    record layout (mkt_core.h KeyRec), per-rank chromosome slots in a rank-dependent order."""
+    MASK1 = 0xFFFFFFFFC000FFFF
+
+    def __init__(self, pairs_lines, rank, lanes=False):
+        import numpy as np
+        names = sorted({f for l in pairs_lines for f in (l.split(b"\t")[1], l.split(b"\t")[3])}, reverse=(rank % 2 == 1))
+        self.slot = {nm: (7 * k + 3 + rank) % 8192 for k, nm in enumerate(names)}
+        k = np.zeros((len(pairs_lines), 3), dtype=np.uint64)
+        for j, l in enumerate(pairs_lines):
+            f = l.split(b"\t")
+            k[j, 0] = (self.slot[f[1]] << 45) | (self.slot[f[3]] << 32) | int(f[2])
+            k[j, 1] = (int(f[4]) << 32) | ((1 if f[5] == b"-" else 0) << 31) | ((1 if f[6] == b"-" else 0) << 30) | (qname_lane(f[0]) if lanes else 0)
+            k[j, 2] = j
+        self.keys = k
+
+    def ext_chr_names(self):
+        return {s: nm for nm, s in self.slot.items()}
+
+    def ext_partition(self, drop_last, lut, world, torch, device):
+        import numpy as np
+        k = self.keys.copy()
+        if k.shape[0]:
+            k0 = k[:, 0]
+            a = lut[((k0 >> np.uint64(45)) & np.uint64(8191)).astype(np.int64)].astype(np.uint64)
+            b = lut[((k0 >> np.uint64(32)) & np.uint64(8191)).astype(np.int64)].astype(np.uint64)
+            k[:, 0] = (a << np.uint64(45)) | (b << np.uint64(32)) | (k0 & np.uint64(0xFFFFFFFF))
+        dest = (_mix64_np(k[:, 0] ^ _mix64_np(k[:, 1] & np.uint64(self.MASK1))) % np.uint64(world)).astype(np.int64)
+        order = np.argsort(dest, kind="stable")
+        self.perm = np.empty(k.shape[0], dtype=np.int64)
+        self.perm[order] = np.arange(k.shape[0])
+        send = torch.from_numpy(np.ascontiguousarray(k[order]).view(np.uint8).reshape(-1).copy())
+        return send, [int((dest == r).sum()) for r in range(world)]
+
+    def ext_dedup_tensor(self, recv, torch):
+        import numpy as np
+        k = recv.numpy().view(np.uint64).reshape(-1, 3)
+        seen = set()
+        flags = np.zeros(k.shape[0], dtype=np.uint8)
+        for j in range(k.shape[0]):
+            key = (int(k[j, 0]), int(k[j, 1]) & self.MASK1)
+            if key in seen:
+                flags[j] = 1
+            seen.add(key)
+        return torch.from_numpy(flags), int(flags.sum())
+
+    def ext_unpartition(self, back, want_flags=True):
+        f = back.numpy()[self.perm] if back.numel() else back.numpy()
+        return bytes(f.tolist()), int(f.sum())
+
+
+class FakeDist:
+    """In-process stand-in for torch.distributed (one THREAD per rank): the collectives dedup_exchange uses, on torch tensors of any
+    device.  Lets two contexts on ONE GPU run the real device-side exchange in the GPU tests."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def rank(self, r):
+        return _FakeRank(self, r)
+
+
+class _FakeRank:
+    def __init__(self, fd, r):
+        self.fd, self.r = fd, r
+
+    def _swap(self, x):
+        self.fd.slots[self.r] = x
+        self.fd.bar.wait()
+        got = list(self.fd.slots)
+        self.fd.bar.wait()
+        return got
+
+    def all_gather_object(self, out, x):
+        out[:] = self._swap(x)
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+        w = self.fd.world
+        if input_split_sizes is None:
+            input_split_sizes = [inp.numel() // w] * w
+        got = self._swap((inp, list(input_split_sizes)))
+        pos = 0
+        for src in range(w):
+            t, sp = got[src]
+            off = sum(sp[:self.r])
+            n = sp[self.r]
+            out[pos:pos + n] = t[off:off + n]
+            pos += n
+        self.fd.bar.wait()
+
+    def all_reduce(self, t):
+        got = self._swap(t.clone())
+        tot = got[0].clone()
+        for x in got[1:]:
+            tot += x
+        t.copy_(tot)
+        self.fd.bar.wait()
