@@ -192,11 +192,9 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend="gloo")
-    else:
-        try:
-            import torch  # noqa: F811  (only for torch.cuda.synchronize around the timed region)
-        except Exception:
-            torch = None
+    # (N = 1 never imports torch: ctx.sync() brackets the timed region.  At N > 1 torch comes first on purpose: its bundled
+    #  libamdhip64.so carries the soname libmkt_hip.so asks for, so the library binds to torch's HIP runtime and the process
+    #  holds ONE runtime; the other order would load two, and the second one sees no GPU.)
 
     import microcket_amd as m
     from microcket_amd import shard

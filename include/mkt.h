@@ -209,6 +209,21 @@ int mkt_ext_unpartition(mkt_ctx* ctx, const uint8_t* d_flags_part, uint8_t* flag
 /* Per-chromosome contact counts of the reported pairs: lines "chrA\tchrB\tcount\n" sorted bytewise by (chrA, chrB). */
 int mkt_ext_chrstat(mkt_ctx* ctx, int drop_last, char* out, size_t cap, size_t* len);
 
+/* ---- .pairs text in the driver's order ----------------------------------------------------
+ * The stage behind sam2pairs is `LANG=C sort -k2,2d -k4,4d -k3,3n -k5,5n` and, to pool the stitched and the unstitched
+ * mode, `sort -m` with the same keys (microcket:480,484,502,506,514).  A sorter takes whole .pairs lines in any
+ * order and any number of pieces (host or device memory), sorts them on the GPU by (chr1 and chr2 in dictionary order
+ * -- blanks and alphanumerics only --, pos1, pos2 numerically, then the whole line bytewise) and hands the text back:
+ * byte for byte what the system's sort prints.  One sorter fed with both modes' pairs replaces sort + sort -m. */
+typedef struct mkt_sorter mkt_sorter;
+int mkt_sorter_create(int device, mkt_sorter** out);
+void mkt_sorter_destroy(mkt_sorter* s);
+const char* mkt_sorter_error(const mkt_sorter* s);
+int mkt_sorter_add(mkt_sorter* s, const char* bytes, size_t n);            /* host bytes (copied before the call returns) */
+int mkt_sorter_add_device(mkt_sorter* s, const void* d_bytes, size_t n);   /* device bytes */
+int mkt_sorter_sort(mkt_sorter* s, uint64_t* lines, uint64_t* bytes);
+int mkt_sorter_fetch(mkt_sorter* s, uint64_t off, char* out, size_t n);    /* sorted bytes [off, off + n) */
+
 /* surviving QNAME groups seen so far (synchronises the context's stream); sharded runs exchange
  * these counts before mkt_finish */
 int mkt_group_count(mkt_ctx* ctx, uint64_t* groups);

@@ -8,9 +8,11 @@ CPU fallback: without the built library or without a GPU every call raises.
 from .capi import (  # noqa: F401
     Context,
     EXT_KEYS,
+    EXT_LANES,
     MktError,
     MODE_FLASH,
     MODE_UNC,
+    PairsSorter,
     TILES_AUTO,
     TILES_FAST,
     TILES_SMALL,
@@ -23,6 +25,6 @@ from .capi import (  # noqa: F401
 )
 
 __all__ = [
-    "Context", "EXT_KEYS", "MktError", "MODE_FLASH", "MODE_UNC", "TILES_AUTO", "TILES_FAST", "TILES_SMALL", "Stats",
+    "Context", "EXT_KEYS", "EXT_LANES", "MktError", "MODE_FLASH", "MODE_UNC", "PairsSorter", "TILES_AUTO", "TILES_FAST", "TILES_SMALL", "Stats",
     "device_count", "exe_path", "lib_path", "load_library", "run_sam2pairs",
 ]

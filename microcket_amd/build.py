@@ -44,8 +44,12 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU build of this package)")
 
 
+def _lib_sources():
+    return [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_sort.hip", "mkt_capi.cpp")]
+
+
 def build_lib(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_capi.cpp")]
+    srcs = _lib_sources()
     deps = srcs + _headers()
     if force or _newer(LIB, deps):
         _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function",
@@ -56,7 +60,7 @@ def build_lib(force=False):
 def build_stamps_lib(name="libmkt_hip_stamps.so", defines=("-DMKT_STAMPS",)):
     """Diagnostic builds (phase stamps / phase ladder / tile-geometry experiments); never loaded by default."""
     out = os.path.join(HERE, name)
-    srcs = [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_capi.cpp")]
+    srcs = _lib_sources()
     _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", *defines, "-Wno-unused-function",
           "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", out])
     return out
@@ -65,7 +69,7 @@ def build_stamps_lib(name="libmkt_hip_stamps.so", defines=("-DMKT_STAMPS",)):
 def build_variant(name, kernel_src=None, defines=()):
     """Experiment builds: another kernel source file and / or extra -D flags -> microcket_amd/<name> (select it with MKT_LIB)."""
     out = os.path.join(HERE, name)
-    srcs = [kernel_src or os.path.join(CSRC, "mkt_kernels.hip"), os.path.join(CSRC, "mkt_capi.cpp")]
+    srcs = [kernel_src or os.path.join(CSRC, "mkt_kernels.hip"), os.path.join(CSRC, "mkt_sort.hip"), os.path.join(CSRC, "mkt_capi.cpp")]
     _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", *defines, "-Wno-unused-function", "-I" + CSRC,
           "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", out])
     return out
@@ -78,6 +82,19 @@ def build_exe(force=False):
         _run(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", src, "-o", EXE, "-L" + HERE, "-lmkt_hip",
               "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
     return EXE
+
+
+PAIRSORT = os.path.join(HERE, "bin", "pairsort")
+
+
+def build_pairsort(force=False):
+    """bin/pairsort: the driver's sort / sort -m step on the GPU."""
+    src = os.path.join(CSRC, "pairsort_main.cpp")
+    if force or _newer(PAIRSORT, [src, LIB] + _headers()):
+        os.makedirs(os.path.dirname(PAIRSORT), exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", PAIRSORT, "-L" + HERE, "-lmkt_hip",
+              "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    return PAIRSORT
 
 
 def build_oracle():
@@ -103,6 +120,7 @@ def build_test_tools():
 def build_all(force=False, extras=True):
     build_lib(force)
     build_exe(force)
+    build_pairsort(force)
     if extras:
         build_oracle()
         build_test_tools()

@@ -15,6 +15,7 @@ EXPORTS = [
     "mkt_submit", "mkt_drain", "mkt_drain_wait", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
+    "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
 ]
 
 
@@ -105,6 +106,15 @@ def load_library():
     L.mkt_ext_partition.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint64)]
     L.mkt_ext_dedup_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)]
     L.mkt_ext_unpartition.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    L.mkt_sorter_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mkt_sorter_destroy.argtypes = [C.c_void_p]
+    L.mkt_sorter_destroy.restype = None
+    L.mkt_sorter_error.argtypes = [C.c_void_p]
+    L.mkt_sorter_error.restype = C.c_char_p
+    L.mkt_sorter_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mkt_sorter_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mkt_sorter_sort.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mkt_sorter_fetch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -367,6 +377,47 @@ class Dataset:
         if self.h:
             self.ctx.L.mkt_dataset_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class PairsSorter:
+    """.pairs text in the driver's order (LANG=C sort -k2,2d -k4,4d -k3,3n -k5,5n) on the GPU: see mkt_sorter_* in include/mkt.h."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        rc = self.L.mkt_sorter_create(device, C.byref(self.h))
+        if rc != 0:
+            raise MktError(f"mkt_sorter_create: {self.L.mkt_strerror(rc).decode()}")
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise MktError(f"{what}: {self.L.mkt_strerror(rc).decode()}: {self.L.mkt_sorter_error(self.h).decode()}")
+
+    def add(self, data: bytes):
+        self._chk(self.L.mkt_sorter_add(self.h, data, len(data)), "mkt_sorter_add")
+
+    def add_device(self, d_ptr, n):
+        self._chk(self.L.mkt_sorter_add_device(self.h, C.c_void_p(d_ptr), n), "mkt_sorter_add_device")
+
+    def sort(self):
+        """Sorts what was added; returns the sorted text."""
+        lines, nbytes = C.c_uint64(), C.c_uint64()
+        self._chk(self.L.mkt_sorter_sort(self.h, C.byref(lines), C.byref(nbytes)), "mkt_sorter_sort")
+        self.lines = lines.value
+        buf = C.create_string_buffer(max(nbytes.value, 1))
+        self._chk(self.L.mkt_sorter_fetch(self.h, 0, buf, nbytes.value), "mkt_sorter_fetch")
+        return buf.raw[:nbytes.value]
+
+    def close(self):
+        if self.h:
+            self.L.mkt_sorter_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes", env=None, exe=None):

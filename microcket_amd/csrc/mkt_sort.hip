@@ -1,0 +1,498 @@
+// mkt_sort.hip -- SURVEY.md 8(f) N1 / N3: .pairs text in the order the driver gives it, on the GPU.
+//
+// The stage right behind sam2pairs in the reference pipeline is GNU sort (microcket:480,484,502,506):
+//     LANG=C sort -k2,2d -k4,4d -k3,3n -k5,5n            and, to pool the two modes,   sort -m ... (microcket:514)
+// i.e. lines ordered by  (chr1 in dictionary order, chr2 in dictionary order, pos1, pos2, whole line bytewise).
+// "Dictionary order" (-d) looks at blanks and alphanumerics only, so chrUn_KI270742v1 sorts as chrUnKI270742v1; with LANG=C
+// everything is a byte comparison.  Here: line index by a newline scan, a 96-bit key per line (dictionary RANK of the two
+// chromosome names, the two positions), a stable LSD radix sort of 16-byte records, whole-line comparison only inside runs
+// of equal keys, and one gather of the lines into the sorted text.  Integer / byte work bound by HBM; no MFMA.
+// The sorted bytes equal `sort`'s byte for byte (tests/test_gpu_sort.py runs the system's sort as the checker).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/mkt.h"
+#include "mkt_launch.h"
+
+using namespace mkt;
+
+namespace mkt {
+
+struct SortRec { uint64_t hi; uint32_t lo; uint32_t idx; };      // hi: rank(chr1) << 48 | rank(chr2) << 32 | pos1 ; lo: pos2 ; idx: line
+
+constexpr int SWG = 256;
+constexpr uint32_t SCHUNK = 1u << 16;                             // text bytes per workgroup in the newline passes
+constexpr uint32_t SSPAN = SCHUNK / SWG;                          // ... and per thread (contiguous)
+enum { SE_FIELDS = 1, SE_NAME = 2, SE_RUN = 4 };
+
+__device__ inline uint32_t blk_exscan(uint32_t v, uint32_t* total, uint32_t* sh /* [SWG / 64] */) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += y; }
+    if (lane == 63) sh[wv] = inc;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SWG / 64; ++w) { if (w < wv) pre += sh[w]; tot += sh[w]; }
+    __syncthreads();
+    *total = tot;
+    return pre + inc - v;
+}
+
+// ---- line index ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SWG) void k_nl_count(const uint8_t* text, uint64_t n, uint64_t* counts) {
+    __shared__ uint32_t sh[SWG / 64];
+    const uint64_t b = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SSPAN;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < SSPAN; ++k) if (b + k < n && text[b + k] == '\n') ++c;
+    uint32_t tot;
+    (void)blk_exscan(c, &tot, sh);
+    if (threadIdx.x == 0) counts[blockIdx.x] = tot;
+}
+// starts[0] = 0, starts[r + 1] = (position of newline r) + 1: line k is text[starts[k], starts[k + 1]) with its newline
+__global__ __launch_bounds__(SWG) void k_nl_starts(const uint8_t* text, uint64_t n, const uint64_t* offs, uint64_t* starts) {
+    __shared__ uint32_t sh[SWG / 64];
+    const uint64_t b = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SSPAN;
+    uint32_t c = 0;
+    for (uint32_t k = 0; k < SSPAN; ++k) if (b + k < n && text[b + k] == '\n') ++c;
+    uint32_t tot;
+    uint64_t r = offs[blockIdx.x] + blk_exscan(c, &tot, sh);
+    for (uint32_t k = 0; k < SSPAN; ++k) if (b + k < n && text[b + k] == '\n') starts[++r] = b + k + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) starts[0] = 0;
+}
+
+// ---- keys ---------------------------------------------------------------------------------------------------
+// rid \t chr1 \t pos1 \t chr2 \t pos2 \t s1 \t s2 \n   (flash2pairs.h:123-127): names into the table, positions as numbers
+__global__ void k_sort_keys(const uint8_t* text, uint64_t n, const uint64_t* starts, uint64_t nlines, ChrTab* tab, SortRec* rec, uint32_t* err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nlines) return;
+    const uint64_t ls = starts[j], le = starts[j + 1] - 1;                    // le: the newline
+    uint64_t tabs[6];
+    int nt = 0;
+    for (uint64_t p = ls; p < le && nt < 6; ++p) if (text[p] == '\t') tabs[nt++] = p;
+    SortRec r;
+    r.hi = 0; r.lo = 0; r.idx = (uint32_t)j;
+    if (nt < 4) { atomicOr(err, (uint32_t)SE_FIELDS); rec[j] = r; return; }
+    const uint64_t p5 = nt >= 5 ? tabs[4] : le;
+    auto num = [&](uint64_t a, uint64_t b) -> uint32_t {                      // sort -n on a plain decimal field
+        uint64_t v = 0;
+        for (uint64_t p = a; p < b; ++p) { const uint32_t d = (uint32_t)text[p] - (uint32_t)'0'; if (d > 9u) { atomicOr(err, (uint32_t)SE_FIELDS); break; } v = v * 10 + d; }
+        if (v > 0xFFFFFFFFull) atomicOr(err, (uint32_t)SE_FIELDS);
+        return (uint32_t)v;
+    };
+    auto slot = [&](uint64_t a, uint64_t b) -> uint32_t {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (uint64_t p = a; p < b; ++p) { h ^= text[p]; h *= 0x100000001b3ull; }
+        if (!h) h = 1;
+        uint32_t s = (uint32_t)(h >> 17) & (kChrSlots - 1u);
+        for (uint32_t probe = 0; probe < kChrSlots; ++probe) {
+            unsigned long long cur = __hip_atomic_load(&tab->hash[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == 0ull) {
+                cur = atomicCAS(&tab->hash[s], 0ull, (unsigned long long)h);
+                if (cur == 0ull) {
+                    const uint32_t m = (uint32_t)(b - a) < kChrNameMax ? (uint32_t)(b - a) : kChrNameMax;
+                    for (uint32_t i = 0; i < m; ++i) tab->name[s][i] = text[a + i];
+                    tab->name[s][63] = (uint8_t)m;
+                    if (b - a > kChrNameMax) atomicOr(err, (uint32_t)SE_NAME);
+                    return s;
+                }
+            }
+            if (cur == h) return s;
+            s = (s + 1u) & (kChrSlots - 1u);
+        }
+        atomicOr(err, (uint32_t)SE_NAME);
+        return 0;
+    };
+    const uint32_t sa = slot(tabs[0] + 1, tabs[1]), sb = slot(tabs[2] + 1, tabs[3]);
+    r.hi = ((uint64_t)sa << 48) | ((uint64_t)sb << 32) | num(tabs[1] + 1, tabs[2]);
+    r.lo = num(tabs[3] + 1, p5);
+    rec[j] = r;
+}
+__global__ void k_sort_ranks(SortRec* rec, uint64_t nlines, const uint16_t* rank_of_slot) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nlines) return;
+    const uint64_t h = rec[j].hi;
+    rec[j].hi = ((uint64_t)rank_of_slot[(h >> 48) & (kChrSlots - 1u)] << 48) | ((uint64_t)rank_of_slot[(h >> 32) & (kChrSlots - 1u)] << 32) | (h & 0xFFFFFFFFull);
+}
+
+// ---- stable LSD radix sort of the 16-byte records, 4-bit digits (ballot ranking) ------------------------------
+__device__ inline uint32_t sort_digit(const SortRec& r, int which, int shift) { return (uint32_t)(((which ? r.hi : (uint64_t)r.lo) >> shift) & 15u); }
+__global__ __launch_bounds__(SWG) void k_rs_hist(const SortRec* rec, uint64_t n, uint64_t per, int which, int shift, uint32_t* hist, uint32_t G) {
+    __shared__ uint32_t cnt[16];
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j = b + threadIdx.x; j < e; j += SWG) atomicAdd(&cnt[sort_digit(rec[j], which, shift)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 16) hist[threadIdx.x * G + blockIdx.x] = cnt[threadIdx.x];
+}
+__global__ __launch_bounds__(SWG) void k_rs_scan(uint32_t* hist, uint32_t m) {
+    __shared__ uint32_t sh[SWG / 64];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < m; base += SWG) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t x = i < m ? hist[i] : 0u;
+        uint32_t tot;
+        const uint32_t e = blk_exscan(x, &tot, sh);
+        if (i < m) hist[i] = carry + e;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(SWG) void k_rs_scatter(const SortRec* rec, uint64_t n, uint64_t per, int which, int shift, const uint32_t* hist, uint32_t G, SortRec* out) {
+    __shared__ uint32_t base[16];
+    __shared__ uint32_t wcnt[SWG / 64][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 16) base[tid] = hist[tid * G + blockIdx.x];
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j0 = b; j0 < e; j0 += SWG) {            // sub-tiles in order keep the pass stable
+        const uint64_t j = j0 + tid;
+        const bool live = j < e;
+        SortRec r;
+        r.hi = 0; r.lo = 0; r.idx = 0;
+        if (live) r = rec[j];
+        const uint32_t d = live ? sort_digit(r, which, shift) : 16u;
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t dd = 0; dd < 16; ++dd) {
+            const uint64_t m = __ballot(d == dd);
+            if (d == dd) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wv][dd] = __popcll(m);
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t o = base[d] + rank;
+            for (int w = 0; w < wv; ++w) o += wcnt[w][d];
+            out[o] = r;
+        }
+        __syncthreads();
+        if (tid < 16) { uint32_t s2 = 0; for (int w = 0; w < SWG / 64; ++w) s2 += wcnt[w][tid]; base[tid] += s2; }
+        __syncthreads();
+    }
+}
+
+// ---- runs of equal keys: the whole line decides (sort's last-resort comparison) ----------------------------------
+__device__ inline bool line_less(const uint8_t* text, const uint64_t* starts, uint32_t a, uint32_t b) {
+    const uint64_t sa = starts[a], sb = starts[b];
+    const uint64_t la = starts[a + 1] - 1 - sa, lb = starts[b + 1] - 1 - sb;      // without the newline
+    const uint64_t m = la < lb ? la : lb;
+    for (uint64_t k = 0; k < m; ++k) {
+        const uint8_t x = text[sa + k], y = text[sb + k];
+        if (x != y) return x < y;
+    }
+    return la < lb;
+}
+__device__ inline bool key_same(const SortRec& x, const SortRec& y) { return x.hi == y.hi && x.lo == y.lo; }
+constexpr uint32_t kSmallRun = 48;
+__global__ void k_tie_small(SortRec* rec, uint64_t n, const uint8_t* text, const uint64_t* starts, uint32_t* big_list, uint32_t* big_count, uint32_t big_cap, uint32_t* err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (j > 0 && key_same(rec[j], rec[j - 1])) return;                    // not the head of a run
+    uint64_t L = 1;
+    while (j + L < n && L <= kSmallRun && key_same(rec[j + L], rec[j])) ++L;
+    if (L == 1) return;
+    if (L > kSmallRun) {
+        const uint32_t k = atomicAdd(big_count, 1u);
+        if (k < big_cap) big_list[k] = (uint32_t)j; else atomicOr(err, (uint32_t)SE_RUN);
+        return;
+    }
+    uint32_t ix[kSmallRun];
+    for (uint32_t k = 0; k < (uint32_t)L; ++k) ix[k] = rec[j + k].idx;
+    for (uint32_t k = 1; k < (uint32_t)L; ++k) {                          // insertion sort (stable; equal lines keep their order)
+        const uint32_t v = ix[k];
+        uint32_t q = k;
+        while (q > 0 && line_less(text, starts, v, ix[q - 1])) { ix[q] = ix[q - 1]; --q; }
+        ix[q] = v;
+    }
+    for (uint32_t k = 0; k < (uint32_t)L; ++k) rec[j + k].idx = ix[k];
+}
+// long runs (heavily duplicated contacts): one workgroup per run ranks every line against all others
+constexpr uint32_t kMaxRun = 1u << 16;
+__global__ __launch_bounds__(SWG) void k_tie_big(SortRec* rec, uint64_t n, const uint8_t* text, const uint64_t* starts, const uint32_t* big_list, uint32_t* tmp, uint32_t* err) {
+    __shared__ uint32_t sL;
+    const uint64_t j = big_list[blockIdx.x];
+    if (threadIdx.x == 0) {
+        uint64_t L = 1;
+        while (j + L < n && key_same(rec[j + L], rec[j])) ++L;
+        sL = L > kMaxRun ? 0u : (uint32_t)L;
+        if (L > kMaxRun) atomicOr(err, (uint32_t)SE_RUN);
+    }
+    __syncthreads();
+    const uint32_t L = sL;
+    for (uint32_t i = threadIdx.x; i < L; i += SWG) {
+        const uint32_t me = rec[j + i].idx;
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < L; ++k) {
+            if (k == i) continue;
+            const uint32_t o = rec[j + k].idx;
+            if (line_less(text, starts, o, me) || (k < i && !line_less(text, starts, me, o))) ++r;
+        }
+        tmp[j + r] = me;
+    }
+    __syncthreads();
+    __threadfence_block();
+    for (uint32_t i = threadIdx.x; i < L; i += SWG) rec[j + i].idx = tmp[j + i];
+}
+
+// ---- gather the lines in sorted order ---------------------------------------------------------------------------
+constexpr uint32_t LPW = 2048;                                              // lines per workgroup in the gather
+__global__ __launch_bounds__(SWG) void k_out_sums(const SortRec* rec, uint64_t n, const uint64_t* starts, uint64_t* wsum) {
+    __shared__ unsigned long long s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * LPW, e = b + LPW < n ? b + LPW : n;
+    unsigned long long mine = 0;
+    for (uint64_t j = b + threadIdx.x; j < e; j += SWG) { const uint32_t i = rec[j].idx; mine += starts[i + 1] - starts[i]; }
+    atomicAdd(&s, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) wsum[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(SWG) void k_out_copy(const SortRec* rec, uint64_t n, const uint8_t* text, const uint64_t* starts, const uint64_t* woff, uint8_t* out) {
+    __shared__ uint32_t sh[SWG / 64];
+    __shared__ uint32_t loff[LPW];
+    const uint64_t b = (uint64_t)blockIdx.x * LPW, e = b + LPW < n ? b + LPW : n;
+    uint32_t carry = 0;
+    for (uint64_t j0 = b; j0 < e; j0 += SWG) {                               // line offsets inside this workgroup's output range
+        const uint64_t j = j0 + threadIdx.x;
+        uint32_t len = 0;
+        if (j < e) { const uint32_t i = rec[j].idx; len = (uint32_t)(starts[i + 1] - starts[i]); }
+        uint32_t tot;
+        const uint32_t ex = blk_exscan(len, &tot, sh);
+        if (j < e) loff[j - b] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();
+    const uint64_t o0 = woff[blockIdx.x];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;              // 16 lanes per line
+    for (uint64_t j = b + grp; j < e; j += SWG / 16) {
+        const uint32_t i = rec[j].idx;
+        const uint64_t s = starts[i];
+        const uint32_t len = (uint32_t)(starts[i + 1] - s);
+        uint8_t* d = out + o0 + loff[j - b];
+        for (uint32_t k = sub; k < len; k += 16) d[k] = text[s + k];
+    }
+}
+
+}  // namespace mkt
+
+// ---------------------------------------------------------------------------------------------------------------
+struct mkt_sorter {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_text = nullptr; size_t cap = 0, len = 0;
+    uint8_t* d_out = nullptr; size_t out_len = 0;
+    uint64_t lines = 0;
+    bool sorted = false;
+    std::string err;
+};
+static int sfail(mkt_sorter* s, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (s) s->err = buf;
+    return code;
+}
+#define SCHK(s, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return sfail((s), MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+static int sorter_reserve(mkt_sorter* s, size_t need) {
+    if (need <= s->cap) return MKT_OK;
+    size_t ncap = s->cap ? s->cap : ((size_t)64 << 20);
+    while (ncap < need) ncap *= 2;
+    uint8_t* nb = nullptr;
+    SCHK(s, hipMalloc((void**)&nb, ncap + 64));
+    if (s->d_text) {
+        SCHK(s, hipStreamSynchronize(s->stream));
+        if (s->len) SCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice));
+        SCHK(s, hipFree(s->d_text));
+    }
+    s->d_text = nb; s->cap = ncap;
+    return MKT_OK;
+}
+
+extern "C" {
+
+int mkt_sorter_create(int device, mkt_sorter** out) {
+    if (!out) return MKT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MKT_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return MKT_E_ARG;
+    mkt_sorter* s = new mkt_sorter();
+    s->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return MKT_E_HIP; }
+    *out = s;
+    return MKT_OK;
+}
+void mkt_sorter_destroy(mkt_sorter* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_text) (void)hipFree(s->d_text);
+    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+const char* mkt_sorter_error(const mkt_sorter* s) { return s ? s->err.c_str() : ""; }
+
+int mkt_sorter_add(mkt_sorter* s, const char* bytes, size_t n) {
+    if (!s || (n && !bytes)) return MKT_E_ARG;
+    if (s->sorted) return sfail(s, MKT_E_STATE, "add after sort");
+    SCHK(s, hipSetDevice(s->device));
+    int rc = sorter_reserve(s, s->len + n + 1);
+    if (rc) return rc;
+    if (n) SCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes, n, hipMemcpyHostToDevice, s->stream));
+    SCHK(s, hipStreamSynchronize(s->stream));                  // the caller may reuse `bytes`
+    s->len += n;
+    return MKT_OK;
+}
+int mkt_sorter_add_device(mkt_sorter* s, const void* d_bytes, size_t n) {
+    if (!s || (n && !d_bytes)) return MKT_E_ARG;
+    if (s->sorted) return sfail(s, MKT_E_STATE, "add after sort");
+    SCHK(s, hipSetDevice(s->device));
+    int rc = sorter_reserve(s, s->len + n + 1);
+    if (rc) return rc;
+    if (n) SCHK(s, hipMemcpyAsync(s->d_text + s->len, d_bytes, n, hipMemcpyDeviceToDevice, s->stream));
+    SCHK(s, hipStreamSynchronize(s->stream));
+    s->len += n;
+    return MKT_OK;
+}
+
+int mkt_sorter_sort(mkt_sorter* s, uint64_t* lines, uint64_t* bytes) {
+    if (!s) return MKT_E_ARG;
+    SCHK(s, hipSetDevice(s->device));
+    if (lines) *lines = 0;
+    if (bytes) *bytes = 0;
+    s->sorted = true;
+    if (s->len == 0) return MKT_OK;
+    {   // whole lines only: a missing final newline is added
+        char last = 0;
+        SCHK(s, hipMemcpy(&last, s->d_text + s->len - 1, 1, hipMemcpyDeviceToHost));
+        if (last != '\n') { const char nl = '\n'; SCHK(s, hipMemcpy(s->d_text + s->len, &nl, 1, hipMemcpyHostToDevice)); ++s->len; }
+    }
+    const uint64_t n = s->len;
+    hipStream_t st = s->stream;
+    const uint32_t chunks = (uint32_t)((n + SCHUNK - 1) / SCHUNK);
+    uint64_t* d_cnt = nullptr;
+    std::vector<void*> owned;
+    auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+#define SALLOC(ptr, bytes_) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes_)); if (e_ != hipSuccess) { cleanup(); return sfail(s, MKT_E_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(bytes_), hipGetErrorString(e_)); } owned.push_back((void*)(ptr)); } while (0)
+#define SRUN(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return sfail(s, MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    SALLOC(d_cnt, ((size_t)chunks + 2) * sizeof(uint64_t));
+    hipLaunchKernelGGL(k_nl_count, dim3(chunks), dim3(SWG), 0, st, (const uint8_t*)s->d_text, n, d_cnt);
+    SRUN(launch_exscan(d_cnt, chunks, d_cnt + chunks, st));
+    uint64_t nl = 0;
+    SRUN(hipMemcpyAsync(&nl, d_cnt + chunks, sizeof nl, hipMemcpyDeviceToHost, st));
+    SRUN(hipStreamSynchronize(st));
+    if (nl >= (1ull << 32)) { cleanup(); return sfail(s, MKT_E_ARG, "%llu lines: the sorter indexes lines with 32 bits", (unsigned long long)nl); }
+    uint64_t* d_starts = nullptr;
+    SortRec *rA = nullptr, *rB = nullptr;
+    ChrTab* d_tab = nullptr;
+    uint32_t *d_hist = nullptr, *d_err = nullptr, *d_big = nullptr, *d_tmp = nullptr;
+    uint16_t* d_rank = nullptr;
+    const uint32_t big_cap = 1u << 20;
+    SALLOC(d_starts, (nl + 2) * sizeof(uint64_t));
+    SALLOC(rA, (nl + 1) * sizeof(SortRec));
+    SALLOC(rB, (nl + 1) * sizeof(SortRec));
+    SALLOC(d_tab, sizeof(ChrTab));
+    SALLOC(d_hist, (size_t)16 * 1024 * 4 + 256);
+    SALLOC(d_err, 256);
+    SALLOC(d_big, (size_t)big_cap * 4);
+    SALLOC(d_rank, kChrSlots * sizeof(uint16_t));
+    SRUN(hipMemsetAsync(d_tab, 0, sizeof(ChrTab), st));
+    SRUN(hipMemsetAsync(d_err, 0, 256, st));
+    hipLaunchKernelGGL(k_nl_starts, dim3(chunks), dim3(SWG), 0, st, (const uint8_t*)s->d_text, n, (const uint64_t*)d_cnt, d_starts);
+    const unsigned lgrid = (unsigned)((nl + 255) / 256);
+    hipLaunchKernelGGL(k_sort_keys, dim3(lgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, n, (const uint64_t*)d_starts, nl, d_tab, rA, d_err);
+    // dictionary ranks of the chromosome names (host: at most 8192 short strings)
+    std::vector<unsigned long long> hh(kChrSlots);
+    std::vector<uint8_t> names((size_t)kChrSlots * 64);
+    uint32_t herr[2] = {0, 0};
+    SRUN(hipMemcpyAsync(hh.data(), d_tab->hash, kChrSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    SRUN(hipMemcpyAsync(names.data(), d_tab->name, names.size(), hipMemcpyDeviceToHost, st));
+    SRUN(hipMemcpyAsync(herr, d_err, sizeof herr, hipMemcpyDeviceToHost, st));
+    SRUN(hipStreamSynchronize(st));
+    if (herr[0]) { cleanup(); return sfail(s, MKT_E_ARG, "not .pairs text (error bits 0x%x: 1 = fewer than five fields / non-decimal position, 2 = chromosome name longer than 62 bytes)", herr[0]); }
+    std::vector<std::pair<std::string, uint32_t>> used;            // (name as sort -d sees it, slot)
+    for (uint32_t k = 0; k < kChrSlots; ++k) if (hh[k]) {
+        std::string f;
+        const uint8_t* nm = &names[(size_t)k * 64];
+        for (uint32_t i = 0; i < nm[63]; ++i) { const uint8_t c = nm[i]; if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == ' ' || c == '\t') f += (char)c; }
+        used.emplace_back(f, k);
+    }
+    std::sort(used.begin(), used.end());                          // bytewise, shorter prefix first: LANG=C
+    std::vector<uint16_t> rank(kChrSlots, 0);
+    uint32_t nr = 0;
+    for (size_t k = 0; k < used.size(); ++k) { if (k && used[k].first != used[k - 1].first) ++nr; rank[used[k].second] = (uint16_t)nr; }
+    int rbits = 1;
+    while ((1u << rbits) <= nr) ++rbits;
+    SRUN(hipMemcpyAsync(d_rank, rank.data(), kChrSlots * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_sort_ranks, dim3(lgrid), dim3(256), 0, st, rA, nl, (const uint16_t*)d_rank);
+    // LSD passes: pos2, pos1, rank(chr2), rank(chr1)
+    uint32_t G = (uint32_t)((nl + 8191) / 8192);
+    if (G > 1024) G = 1024;
+    if (G == 0) G = 1;
+    const uint64_t per = (nl + G - 1) / G;
+    auto pass = [&](int which, int shift) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, nl, per, which, shift, d_hist, G);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(SWG), 0, st, d_hist, 16u * G);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, nl, per, which, shift, (const uint32_t*)d_hist, G, rB);
+        std::swap(rA, rB);
+    };
+    for (int sh = 0; sh < 32; sh += 4) pass(0, sh);
+    for (int sh = 0; sh < 32; sh += 4) pass(1, sh);
+    for (int sh = 0; sh < rbits; sh += 4) pass(1, 32 + sh);
+    for (int sh = 0; sh < rbits; sh += 4) pass(1, 48 + sh);
+    // whole-line order inside runs of equal keys
+    hipLaunchKernelGGL(k_tie_small, dim3(lgrid), dim3(256), 0, st, rA, nl, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, d_big, d_err + 1, big_cap, d_err);
+    SRUN(hipMemcpyAsync(herr, d_err, sizeof herr, hipMemcpyDeviceToHost, st));
+    SRUN(hipStreamSynchronize(st));
+    if (herr[1]) {
+        if (herr[1] > big_cap) { cleanup(); return sfail(s, MKT_E_CAPACITY, "more than %u long runs of equal sort keys", big_cap); }
+        SALLOC(d_tmp, (nl + 1) * sizeof(uint32_t));
+        hipLaunchKernelGGL(k_tie_big, dim3(herr[1]), dim3(SWG), 0, st, rA, nl, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, (const uint32_t*)d_big, d_tmp, d_err);
+        SRUN(hipMemcpyAsync(herr, d_err, sizeof herr, hipMemcpyDeviceToHost, st));
+        SRUN(hipStreamSynchronize(st));
+    }
+    if (herr[0] & SE_RUN) { cleanup(); return sfail(s, MKT_E_CAPACITY, "a run of more than %u lines with the same (chr1, chr2, pos1, pos2)", kMaxRun); }
+    // gather
+    const uint32_t wg = (uint32_t)((nl + LPW - 1) / LPW);
+    uint64_t* d_wsum = nullptr;
+    SALLOC(d_wsum, ((size_t)wg + 2) * sizeof(uint64_t));
+    if (s->d_out) { (void)hipFree(s->d_out); s->d_out = nullptr; }
+    { hipError_t e_ = hipMalloc((void**)&s->d_out, n + 64); if (e_ != hipSuccess) { cleanup(); return sfail(s, MKT_E_NOMEM, "hipMalloc of the sorted text failed: %s", hipGetErrorString(e_)); } }
+    hipLaunchKernelGGL(k_out_sums, dim3(wg), dim3(SWG), 0, st, (const SortRec*)rA, nl, (const uint64_t*)d_starts, d_wsum);
+    SRUN(launch_exscan(d_wsum, wg, d_wsum + wg, st));
+    hipLaunchKernelGGL(k_out_copy, dim3(wg), dim3(SWG), 0, st, (const SortRec*)rA, nl, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, (const uint64_t*)d_wsum, s->d_out);
+    SRUN(hipGetLastError());
+    SRUN(hipStreamSynchronize(st));
+    cleanup();
+#undef SALLOC
+#undef SRUN
+    s->out_len = n; s->lines = nl;
+    if (lines) *lines = nl;
+    if (bytes) *bytes = n;
+    return MKT_OK;
+}
+
+int mkt_sorter_fetch(mkt_sorter* s, uint64_t off, char* out, size_t n) {
+    if (!s || (n && !out)) return MKT_E_ARG;
+    if (!s->sorted) return sfail(s, MKT_E_STATE, "fetch before sort");
+    if (off + n > s->out_len) return sfail(s, MKT_E_ARG, "range past the end of the sorted text");
+    SCHK(s, hipSetDevice(s->device));
+    if (n) SCHK(s, hipMemcpy(out, s->d_out + off, n, hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+}  // extern "C"

@@ -10,10 +10,17 @@
 //   MKT_BLOCK_MB     SAM megabytes per GPU pass (default 64)
 //   MKT_IO_THREADS   threads that read a regular input file / write big .sam chunks (default 8)
 //   MKT_TILES        auto | fast | small
+//   MKT_SORTED=1     stdout in the driver's own order (LANG=C sort -k2,2d -k4,4d -k3,3n -k5,5n, microcket:480): the pairs are
+//                    kept on the GPU, sorted there at the end of the input and written then; `sort` behind it only verifies
+//   MKT_HEADER=file  with MKT_SORTED: the bytes of `file` (anno/4DN.DCIC.header) in front of the pairs (microcket:468)
 //   MKT_EXT=1        extensions (never change stdout / .sam / .log): also writes
 //                      <prefix>.<mode>.chrstat     chrA \t chrB \t count   (reported pairs per chromosome pair)
 //                      <prefix>.<mode>.dedup.stat  Total / Uniq / Dup of the pairs-level duplicate marking
 //                      <prefix>.<mode>.dups        0-based ordinals (input order) of the reported pairs that are duplicates
+//                      <prefix>.<mode>.dedup.pairs the reported pairs without those duplicates, in input order.  Survivor rule:
+//                                                  of the pairs with one (chr1, pos1, chr2, pos2, strand1, strand2) [+ lane with
+//                                                  MKT_EXT_LANES=1, the driver's -b] the FIRST in input order stays
+//                    (MKT_EXT=1 switches the run to input-order output: stdout is then deterministic bytes)
 #include <atomic>
 #include <cerrno>
 #include <cstdio>
@@ -79,7 +86,16 @@ int main(int argc, char* argv[]) {
     if ((e = getenv("MKT_TILES"))) p.tiles = !strcmp(e, "small") ? MKT_TILES_SMALL : !strcmp(e, "fast") ? MKT_TILES_FAST : MKT_TILES_AUTO;
 
     const bool ext = (e = getenv("MKT_EXT")) && e[0] == '1';
-    if (ext) p.extensions = MKT_EXT_KEYS;
+    if (ext) {
+        p.extensions = MKT_EXT_KEYS;
+        if ((e = getenv("MKT_EXT_LANES")) && e[0] == '1') p.extensions |= MKT_EXT_LANES;
+        p.ordered = 1;                 // .dedup.pairs pairs the lines with their duplicate flags by input order
+    }
+    FILE* ftee = nullptr;              // extensions: the reported pairs once more, filtered into .dedup.pairs at the end
+    if (ext) {
+        ftee = fopen((base + ".dedup.pairs.tmp").c_str(), "wb+");
+        if (!ftee) { std::cerr << "Error: write dedup.pairs file failed!\n"; return 11; }
+    }
     const bool verbose = (e = getenv("MKT_VERBOSE")) && e[0] == '1';     // wall-clock marks on stderr (diagnostics only)
     const auto t_start = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
@@ -91,6 +107,11 @@ int main(int argc, char* argv[]) {
     if (rc != MKT_OK) {
         std::cerr << "Error: GPU context: " << mkt_strerror(rc) << ": " << mkt_last_error(nullptr) << "\n";
         return 20;
+    }
+    mkt_sorter* sorter = nullptr;
+    if ((e = getenv("MKT_SORTED")) && e[0] == '1') {
+        rc = mkt_sorter_create(p.device, &sorter);
+        if (rc != MKT_OK) { std::cerr << "Error: GPU sorter: " << mkt_strerror(rc) << "\n"; return 20; }
     }
     // Outputs: a writer thread takes the published chunks straight out of the library's pinned staging buffers
     // (mkt_drain_wait) while this thread keeps reading; a slow consumer of stdout throttles the pipeline by itself.
@@ -118,7 +139,11 @@ int main(int argc, char* argv[]) {
             const int wrc = mkt_drain_wait(ctx, &o, &done);
             if (wrc != MKT_OK) { drain_rc = wrc; break; }
             if (!write_failed) {
-                if (o.pairs_len && !write_all(1, o.pairs, o.pairs_len)) write_failed = 1;
+                if (o.pairs_len && ftee && fwrite(o.pairs, 1, o.pairs_len, ftee) != o.pairs_len) write_failed = 1;
+                if (o.pairs_len) {
+                    if (sorter) { if (mkt_sorter_add(sorter, o.pairs, o.pairs_len) != MKT_OK) write_failed = 2; }      // back to the GPU: sorted at the end
+                    else if (!write_all(1, o.pairs, o.pairs_len)) write_failed = 1;
+                }
                 if (fsam && o.sam_len) {
                     if (sam_regular && o.sam_len >= ((size_t)8 << 20) && io_threads > 1) {
                         // the page-cache copy of one thread is a few GB/s: big chunks go out as disjoint pwrite slices
@@ -222,6 +247,23 @@ int main(int argc, char* argv[]) {
     if (drain_rc) { std::cerr << "Error: " << mkt_strerror(drain_rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
     if (write_failed) { std::cerr << "Error: write output failed!\n"; return 22; }
     if (fsam) fclose(fsam);
+    if (sorter) {
+        if ((e = getenv("MKT_HEADER"))) {
+            std::ifstream fh(e, std::ios::binary);
+            if (fh.fail()) { std::cerr << "Error: read header file failed!\n"; return 10; }
+            std::string hdr((std::istreambuf_iterator<char>(fh)), std::istreambuf_iterator<char>());
+            if (!write_all(1, hdr.data(), hdr.size())) { std::cerr << "Error: write output failed!\n"; return 22; }
+        }
+        uint64_t lines = 0, bytes = 0;
+        rc = mkt_sorter_sort(sorter, &lines, &bytes);
+        if (rc != MKT_OK) { std::cerr << "Error: GPU sorter: " << mkt_strerror(rc) << ": " << mkt_sorter_error(sorter) << "\n"; return 21; }
+        std::vector<char> piece((size_t)64 << 20);
+        for (uint64_t off = 0; off < bytes; off += piece.size()) {
+            const size_t k = bytes - off < piece.size() ? (size_t)(bytes - off) : piece.size();
+            if (mkt_sorter_fetch(sorter, off, piece.data(), k) != MKT_OK || !write_all(1, piece.data(), k)) { std::cerr << "Error: write output failed!\n"; return 22; }
+        }
+        mark("sorted output");
+    }
 
     std::ofstream flog((base + "2pairs.log").c_str());     // sam2pairs.cpp:195-219
     if (flog.fail()) { std::cerr << "Error: write log file failed!\n"; return 10; }
@@ -238,6 +280,29 @@ int main(int argc, char* argv[]) {
         fd << "Total\t" << total << "\nUniq\t" << (total - dups) << "\nDup\t" << dups << "\n";
         std::ofstream fl((base + ".dups").c_str());
         for (uint64_t k = 0; k < total; ++k) if (flags[k]) fl << k << "\n";
+        {   // .dedup.pairs: line k of the (input-order) pairs stays unless flags[k]
+            FILE* fo = fopen((base + ".dedup.pairs").c_str(), "wb");
+            if (!fo) { std::cerr << "Error: write dedup.pairs file failed!\n"; return 11; }
+            fflush(ftee);
+            rewind(ftee);
+            std::vector<char> ib((size_t)8 << 20), ob;
+            ob.reserve(ib.size());
+            uint64_t k = 0;
+            size_t got;
+            while ((got = fread(ib.data(), 1, ib.size(), ftee)) > 0) {
+                ob.clear();
+                for (size_t q = 0; q < got; ++q) {
+                    const char ch = ib[q];
+                    if (k >= total || !flags[k]) ob.push_back(ch);
+                    if (ch == '\n') ++k;
+                }
+                if (!ob.empty() && fwrite(ob.data(), 1, ob.size(), fo) != ob.size()) { std::cerr << "Error: write dedup.pairs file failed!\n"; return 22; }
+            }
+            fclose(fo);
+            fclose(ftee);
+            remove((base + ".dedup.pairs.tmp").c_str());
+            if (k != total) { std::cerr << "Error: dedup.pairs: " << k << " lines for " << total << " flags\n"; return 21; }
+        }
         size_t len = 0;
         mkt_ext_chrstat(ctx, 1, nullptr, 0, &len);
         std::vector<char> txt(len + 1);

@@ -86,6 +86,11 @@ def test_executable_side_files(tmp_path):
     assert (tmp_path / "o.unc.chrstat").read_bytes() == want_stat
     assert (tmp_path / "o.unc.dedup.stat").read_text() == f"Total\t{len(want_flags)}\nUniq\t{len(want_flags) - sum(want_flags)}\nDup\t{sum(want_flags)}\n"
     assert (tmp_path / "o.unc.dups").read_text() == "".join(f"{k}\n" for k, f in enumerate(want_flags) if f)
+    # <prefix>.<mode>.dedup.pairs: the reported pairs in input order without the duplicates (first in input order stays)
+    lines = po.split(b"\n")[:-1]
+    assert p.stdout == po                                    # MKT_EXT=1 runs in input order
+    assert (tmp_path / "o.unc.dedup.pairs").read_bytes() == b"".join(l + b"\n" for l, f in zip(lines, want_flags) if not f)
+    assert not (tmp_path / "o.unc.dedup.pairs.tmp").exists()
 
 
 def test_sharded_dedup_equals_single_context():
@@ -151,48 +156,17 @@ def test_lane_scoped_duplicates_like_the_drivers_b_switch():
 
 @pytest.mark.parametrize("lanes", [False, True])
 def test_hash_partitioned_exchange_on_device(lanes):
-    """The xGMI design of the sharded duplicate marking with its REAL device side: two contexts = two shards on one GPU, one
+    """The xGMI design of the sharded duplicate marking with its REAL device side: world contexts = world shards on one GPU, one
     thread per rank, microcket_amd.shard.dedup_exchange over an in-process stand-in for torch.distributed (the collectives
     move torch CUDA tensors; bench.py passes torch.distributed with the nccl = RCCL backend).  Partition, remap, marking
-    of the received records and the way back all run as HIP kernels; the flags must equal the single-context result."""
+    of the received records and the way back all run as HIP kernels; the flags must equal the single-context result.
+    Runs in a process of its own (tests/gpu_exchange_check.py): PyTorch has to be imported BEFORE libmkt_hip.so is loaded --
+    torch/lib/libamdhip64.so carries the soname the library asks for, so the library then shares torch's HIP runtime; the
+    other way round the process would hold two runtimes and torch would see no GPU."""
     if m.device_count() < 1:
         pytest.fail("no HIP device")
-    import threading
-    import torch
-    from microcket_amd import shard
-    ext = m.EXT_KEYS | (m.EXT_LANES if lanes else 0)
-    text = _dup_heavy(5000, lanes=4) + util.synth("unc", 71, 3000, 100, "mm10", 4)
-    with m.Context("unc", 0.5, 10, False, 4, device=0, extensions=ext, ordered=True) as c:
-        c.run_bytes(text)
-        total, dups, want = c.ext_dedup(True)
-    po = util.oracle_run(text, "unc", 4, 0.5, 10, False)[0]
-    assert want == util.expected_dups(po, lanes)
-    for world in (2, 3):
-        cuts = shard.cut_points(text, world, min_mapq=10)
-        ctxs = [m.Context("unc", 0.5, 10, False, 4, device=0, extensions=ext) for _ in range(world)]
-        for r in reversed(range(world)):      # the name tables fill in different orders
-            ctxs[r].submit(text[cuts[r]:cuts[r + 1]], last=True)
-        counts = [c.group_count() for c in ctxs]
-        for r, c in enumerate(ctxs):
-            c.finish(drop_last=(r == world - 1), group_offset=sum(counts[:r]), total_groups=sum(counts))
-        fd = util.FakeDist(world)
-        res = [None] * world
-        err = []
-
-        def run(r):
-            try:
-                res[r] = shard.dedup_exchange(ctxs[r], r, world, r == world - 1, fd.rank(r), torch, "cuda:0")
-            except Exception as ex:          # a dead rank must not leave the others at a barrier
-                err.append(ex)
-                fd.bar.abort()
-
-        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        for c in ctxs:
-            c.close()
-        assert not err, err
-        assert b"".join(res[r][0] for r in range(world)) == want
-        assert sum(res[r][1] for r in range(world)) == dups and all(res[r][2] == dups for r in range(world))
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_exchange_check.py"), "1" if lanes else "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0 and b"exchange ok" in p.stdout, p.stdout.decode()[-3000:]
