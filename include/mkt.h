@@ -224,6 +224,21 @@ int mkt_sorter_add_device(mkt_sorter* s, const void* d_bytes, size_t n);   /* de
 int mkt_sorter_sort(mkt_sorter* s, uint64_t* lines, uint64_t* bytes);
 int mkt_sorter_fetch(mkt_sorter* s, uint64_t off, char* out, size_t n);    /* sorted bytes [off, off + n) */
 
+/* ---- FASTQ duplicate removal: the reference's krmdup / krmdup.pipe ---------------------------------
+ * Replaces src/preprocess/krmdup.cpp:88-227 and krmdup.pipe.cpp:80-205: interleaved paired-end FASTQ in; out the pairs whose
+ * 64-bit key (2 bits per base over seq1[hskip1, hskip1 + keylen1) and seq2[hskip2, hskip2 + keylen2), C=0 A=1 T=2 G=3)
+ * was not seen before -- first seen wins, one key set per first key base, output order and the Total / Uniq / Dup / Discard
+ * counters exactly as the reference's -- either as read-1 and read-2 records (krmdup) or interleaved (krmdup.pipe).  The
+ * drop-ins for the process contract are bin/krmdup and bin/krmdup.pipe (microcket_amd/csrc/krmdup_main.cpp). */
+typedef struct mkt_rmdup mkt_rmdup;
+int mkt_rmdup_create(int device, mkt_rmdup** out);
+void mkt_rmdup_destroy(mkt_rmdup* r);
+const char* mkt_rmdup_error(const mkt_rmdup* r);
+int mkt_rmdup_add(mkt_rmdup* r, const char* bytes, size_t n);       /* the next bytes of the FASTQ stream (host; copied) */
+int mkt_rmdup_run(mkt_rmdup* r, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved,
+                  uint64_t stats[4] /* total, uniq, dup, discard */, uint64_t out_bytes[2]);
+int mkt_rmdup_fetch(mkt_rmdup* r, int which /* 0: read 1 or the interleaved stream, 1: read 2 */, uint64_t off, char* out, size_t n);
+
 /* surviving QNAME groups seen so far (synchronises the context's stream); sharded runs exchange
  * these counts before mkt_finish */
 int mkt_group_count(mkt_ctx* ctx, uint64_t* groups);

@@ -21,10 +21,11 @@ from .capi import (  # noqa: F401
     exe_path,
     lib_path,
     load_library,
+    rmdup,
     run_sam2pairs,
 )
 
 __all__ = [
     "Context", "EXT_KEYS", "EXT_LANES", "MktError", "MODE_FLASH", "MODE_UNC", "PairsSorter", "TILES_AUTO", "TILES_FAST", "TILES_SMALL", "Stats",
-    "device_count", "exe_path", "lib_path", "load_library", "run_sam2pairs",
+    "device_count", "exe_path", "lib_path", "load_library", "rmdup", "run_sam2pairs",
 ]

@@ -97,6 +97,23 @@ def build_pairsort(force=False):
     return PAIRSORT
 
 
+KRMDUP = os.path.join(HERE, "bin", "krmdup")
+KRMDUP_PIPE = os.path.join(HERE, "bin", "krmdup.pipe")
+
+
+def build_krmdup(force=False):
+    """bin/krmdup and bin/krmdup.pipe: drop-ins for the reference's FASTQ duplicate removal; one program,
+    the interleaved-stdout form is chosen by its name."""
+    src = os.path.join(CSRC, "krmdup_main.cpp")
+    if force or _newer(KRMDUP, [src, LIB] + _headers()):
+        os.makedirs(os.path.dirname(KRMDUP), exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", KRMDUP, "-L" + HERE, "-lmkt_hip",
+              "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    if force or _newer(KRMDUP_PIPE, [KRMDUP]):
+        shutil.copy2(KRMDUP, KRMDUP_PIPE)
+    return KRMDUP
+
+
 def build_oracle():
     """Test infrastructure: CPU restatement (+ the reference itself when /root/reference is present)."""
     _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
@@ -121,6 +138,7 @@ def build_all(force=False, extras=True):
     build_lib(force)
     build_exe(force)
     build_pairsort(force)
+    build_krmdup(force)
     if extras:
         build_oracle()
         build_test_tools()

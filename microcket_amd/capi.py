@@ -16,6 +16,7 @@ EXPORTS = [
     "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
     "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
+    "mkt_rmdup_create", "mkt_rmdup_destroy", "mkt_rmdup_error", "mkt_rmdup_add", "mkt_rmdup_run", "mkt_rmdup_fetch",
 ]
 
 
@@ -115,6 +116,14 @@ def load_library():
     L.mkt_sorter_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mkt_sorter_sort.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mkt_sorter_fetch.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]
+    L.mkt_rmdup_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mkt_rmdup_destroy.argtypes = [C.c_void_p]
+    L.mkt_rmdup_destroy.restype = None
+    L.mkt_rmdup_error.argtypes = [C.c_void_p]
+    L.mkt_rmdup_error.restype = C.c_char_p
+    L.mkt_rmdup_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mkt_rmdup_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mkt_rmdup_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -418,6 +427,36 @@ class PairsSorter:
 
     def __exit__(self, *a):
         self.close()
+
+
+def rmdup(text: bytes, hskip1=5, keylen1=16, hskip2=5, keylen2=16, interleaved=False, device=0, piece=1 << 24):
+    """The reference's krmdup on the GPU (mkt_rmdup_*): returns (read1 | interleaved bytes, read2 bytes, (total, uniq, dup, discard))."""
+    L = load_library()
+    h = C.c_void_p()
+    rc = L.mkt_rmdup_create(device, C.byref(h))
+    if rc != 0:
+        raise MktError(f"mkt_rmdup_create: {L.mkt_strerror(rc).decode()}")
+    try:
+        for k in range(0, len(text), piece):
+            part = text[k:k + piece]
+            rc = L.mkt_rmdup_add(h, part, len(part))
+            if rc != 0:
+                raise MktError(f"mkt_rmdup_add: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+        st = (C.c_uint64 * 4)()
+        ob = (C.c_uint64 * 2)()
+        rc = L.mkt_rmdup_run(h, hskip1, keylen1, hskip2, keylen2, 1 if interleaved else 0, st, ob)
+        if rc != 0:
+            raise MktError(f"mkt_rmdup_run: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+        outs = []
+        for which in (0, 1):
+            buf = C.create_string_buffer(max(ob[which], 1))
+            rc = L.mkt_rmdup_fetch(h, which, 0, buf, ob[which])
+            if rc != 0:
+                raise MktError(f"mkt_rmdup_fetch: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+            outs.append(buf.raw[:ob[which]])
+        return outs[0], outs[1], tuple(int(x) for x in st)
+    finally:
+        L.mkt_rmdup_destroy(h)
 
 
 def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes", env=None, exe=None):

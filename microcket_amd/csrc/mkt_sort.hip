@@ -496,3 +496,317 @@ int mkt_sorter_fetch(mkt_sorter* s, uint64_t off, char* out, size_t n) {
 }
 
 }  // extern "C"
+
+
+// =================================================================================================================
+// the reference's duplicate removal, krmdup / krmdup.pipe (src/preprocess/krmdup.cpp:88-227), on the GPU.
+// Interleaved paired-end FASTQ (8 lines per pair) -> the pairs whose 64-bit key (2 bits per base over seq1[hskip1, epos1)
+// and seq2[hskip2, epos2), C=0 A=1 T=2 G=3) was not seen before, in the reference's output order, plus its four counters.
+// Same building blocks as the sorter above: newline index, 16-byte records, stable LSD radix sort; "first seen wins" is the
+// first record of every run of equal (bucket, key) after the stable sort.  Bit-exact against the compiled reference
+// (tests/test_gpu_krmdup.py, golden vectors made by oracle/_ref/krmdup.ref).
+namespace mkt {
+
+struct RmParams { uint32_t hskip1, epos1, hskip2, epos2; };
+constexpr uint32_t RM_BATCH = 1u << 16;                      // krmdup.cpp:19
+
+// one record per pair: hi = key, lo = bucket (0 A, 1 C, 2 G, 3 everything else; 4 = discarded), idx = pair
+__global__ void k_rm_keys(const uint8_t* text, const uint64_t* starts, uint64_t npairs, RmParams P, SortRec* rec) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npairs) return;
+    const uint64_t s1 = starts[8 * r + 1], l1 = starts[8 * r + 2] - 1 - s1;      // seq1 without its newline
+    const uint64_t s2 = starts[8 * r + 5], l2 = starts[8 * r + 6] - 1 - s2;
+    SortRec o;
+    o.hi = 0; o.lo = 4; o.idx = (uint32_t)r;
+    uint8_t first = 'N';
+    if (l1 >= P.epos1) first = text[s1 + P.hskip1];                              // krmdup.cpp:105-108
+    if (first != 'N' && l2 >= P.epos2) {                                         // :110 / :157
+        uint64_t key = 0;
+        bool bad = false;
+        auto code = [&](uint8_t c) -> uint32_t {                                 // :171-176
+            if (c == 'A' || c == 'a') return 1u;
+            if (c == 'T' || c == 't') return 2u;
+            if (c == 'C' || c == 'c') return 0u;
+            if (c == 'G' || c == 'g') return 3u;
+            bad = true;
+            return 0u;
+        };
+        for (uint32_t i = P.hskip1; i != P.epos1; ++i) key = (key << 2) | code(text[s1 + i]);
+        for (uint32_t i = P.hskip2; i != P.epos2; ++i) key = (key << 2) | code(text[s2 + i]);
+        if (!bad) { o.hi = key; o.lo = first == 'A' ? 0u : (first == 'C' ? 1u : (first == 'G' ? 2u : 3u)); }
+    }
+    rec[r] = o;
+}
+// after the stable sort by (bucket, key): the first record of a run stays.  state[pair]: 0 discarded, 1 duplicate, 2 + bucket kept
+__global__ void k_rm_mark(const SortRec* rec, uint64_t n, uint8_t* state, unsigned long long* counts /* uniq, dup, discard */) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t u = 0, d = 0, x = 0;
+    if (j < n) {
+        const SortRec r = rec[j];
+        if (r.lo >= 4u) { state[r.idx] = 0; x = 1; }
+        else if (j > 0 && rec[j - 1].lo == r.lo && rec[j - 1].hi == r.hi) { state[r.idx] = 1; d = 1; }
+        else { state[r.idx] = (uint8_t)(2u + r.lo); u = 1; }
+    }
+    const uint64_t bu = __ballot(u), bd = __ballot(d), bx = __ballot(x);
+    if ((threadIdx.x & 63) == 0) {
+        if (bu) atomicAdd(&counts[0], (unsigned long long)__popcll(bu));
+        if (bd) atomicAdd(&counts[1], (unsigned long long)__popcll(bd));
+        if (bx) atomicAdd(&counts[2], (unsigned long long)__popcll(bx));
+    }
+}
+// output order (krmdup.cpp:215-226): batch after batch of 2^16 input pairs; inside a batch bucket A's survivors, then C's, G's, T's,
+// each in input order.  One workgroup per batch: kept pairs per bucket (pass 0), then their slots (pass 1, base[] from the host scan).
+__global__ __launch_bounds__(SWG) void k_rm_order(const uint8_t* state, uint64_t npairs, const uint64_t* base /* [nbatch][4], pass 1 */, uint32_t* cnt /* [nbatch][4], pass 0 */,
+                                                  uint32_t* order, int pass) {
+    __shared__ uint32_t sh[SWG / 64];
+    const uint64_t b0 = (uint64_t)blockIdx.x * RM_BATCH, b1 = b0 + RM_BATCH < npairs ? b0 + RM_BATCH : npairs;
+    for (uint32_t bucket = 0; bucket < 4u; ++bucket) {
+        uint64_t run = pass ? base[(uint64_t)blockIdx.x * 4 + bucket] : 0;
+        uint32_t total = 0;
+        for (uint64_t r0 = b0; r0 < b1; r0 += SWG) {
+            const uint64_t r = r0 + threadIdx.x;
+            const uint32_t f = (r < b1 && state[r] == 2u + bucket) ? 1u : 0u;
+            uint32_t tot;
+            const uint32_t ex = blk_exscan(f, &tot, sh);
+            if (pass && f) order[run + ex] = (uint32_t)r;
+            run += tot; total += tot;
+        }
+        if (!pass && threadIdx.x == 0) cnt[(uint64_t)blockIdx.x * 4 + bucket] = total;
+    }
+}
+// record lengths in output order: "id\nseq\n+\nqual\n" = len(id) + len(seq) + len(qual) + 5   (krmdup.cpp:206-209)
+__device__ inline uint64_t rm_reclen(const uint64_t* starts, uint64_t r, int mate) {
+    const uint64_t l = 8 * r + 4 * (uint64_t)mate;
+    return (starts[l + 1] - 1 - starts[l]) + (starts[l + 2] - 1 - starts[l + 1]) + (starts[l + 4] - 1 - starts[l + 3]) + 5u;
+}
+constexpr uint32_t RPW = 1024;                                // records per workgroup in the gather
+// which: 0 read 1, 1 read 2, 2 both interleaved (krmdup.pipe.cpp:197-199)
+__global__ __launch_bounds__(SWG) void k_rm_sums(const uint32_t* order, uint64_t nkept, const uint64_t* starts, int which, uint64_t* wsum) {
+    __shared__ unsigned long long s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * RPW, e = b + RPW < nkept ? b + RPW : nkept;
+    unsigned long long mine = 0;
+    for (uint64_t j = b + threadIdx.x; j < e; j += SWG) {
+        const uint64_t r = order[j];
+        mine += which == 2 ? rm_reclen(starts, r, 0) + rm_reclen(starts, r, 1) : rm_reclen(starts, r, which);
+    }
+    atomicAdd(&s, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) wsum[blockIdx.x] = s;
+}
+__device__ inline void rm_copy_rec(const uint8_t* text, const uint64_t* starts, uint64_t r, int mate, uint8_t* d, int sub, int nsub) {
+    const uint64_t l = 8 * r + 4 * (uint64_t)mate;
+    const uint64_t a0 = starts[l], a1 = starts[l + 1], a3 = starts[l + 3];
+    const uint64_t n0 = starts[l + 1] - a0, n1 = starts[l + 2] - a1, n3 = starts[l + 4] - a3;       // with their newlines
+    for (uint64_t k = sub; k < n0; k += nsub) d[k] = text[a0 + k];
+    for (uint64_t k = sub; k < n1; k += nsub) d[n0 + k] = text[a1 + k];
+    if (sub == 0) { d[n0 + n1] = '+'; d[n0 + n1 + 1] = '\n'; }                                       // the third line becomes a bare "+"
+    for (uint64_t k = sub; k < n3; k += nsub) d[n0 + n1 + 2 + k] = text[a3 + k];
+}
+__global__ __launch_bounds__(SWG) void k_rm_copy(const uint32_t* order, uint64_t nkept, const uint8_t* text, const uint64_t* starts, int which, const uint64_t* woff, uint8_t* out) {
+    __shared__ uint32_t sh[SWG / 64];
+    __shared__ uint32_t loff[RPW];
+    const uint64_t b = (uint64_t)blockIdx.x * RPW, e = b + RPW < nkept ? b + RPW : nkept;
+    uint32_t carry = 0;
+    for (uint64_t j0 = b; j0 < e; j0 += SWG) {
+        const uint64_t j = j0 + threadIdx.x;
+        uint32_t len = 0;
+        if (j < e) { const uint64_t r = order[j]; len = (uint32_t)(which == 2 ? rm_reclen(starts, r, 0) + rm_reclen(starts, r, 1) : rm_reclen(starts, r, which)); }
+        uint32_t tot;
+        const uint32_t ex = blk_exscan(len, &tot, sh);
+        if (j < e) loff[j - b] = carry + ex;
+        carry += tot;
+    }
+    __syncthreads();
+    const uint64_t o0 = woff[blockIdx.x];
+    const int sub = threadIdx.x & 31, grp = threadIdx.x >> 5;              // 32 lanes per record
+    for (uint64_t j = b + grp; j < e; j += SWG / 32) {
+        const uint64_t r = order[j];
+        uint8_t* d = out + o0 + loff[j - b];
+        if (which == 2) { rm_copy_rec(text, starts, r, 0, d, sub, 32); rm_copy_rec(text, starts, r, 1, d + rm_reclen(starts, r, 0), sub, 32); }
+        else rm_copy_rec(text, starts, r, which, d, sub, 32);
+    }
+}
+
+}  // namespace mkt
+
+struct mkt_rmdup {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_text = nullptr; size_t cap = 0, len = 0;
+    uint8_t* d_out[3] = {nullptr, nullptr, nullptr}; uint64_t out_len[3] = {0, 0, 0};
+    bool done = false;
+    std::string err;
+};
+static int rfail(mkt_rmdup* s, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (s) s->err = buf;
+    return code;
+}
+#define RCHK(s, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return rfail((s), MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+extern "C" {
+
+int mkt_rmdup_create(int device, mkt_rmdup** out) {
+    if (!out) return MKT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MKT_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return MKT_E_ARG;
+    mkt_rmdup* s = new mkt_rmdup();
+    s->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return MKT_E_HIP; }
+    *out = s;
+    return MKT_OK;
+}
+void mkt_rmdup_destroy(mkt_rmdup* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_text) (void)hipFree(s->d_text);
+    for (int k = 0; k < 3; ++k) if (s->d_out[k]) (void)hipFree(s->d_out[k]);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+const char* mkt_rmdup_error(const mkt_rmdup* s) { return s ? s->err.c_str() : ""; }
+
+int mkt_rmdup_add(mkt_rmdup* s, const char* bytes, size_t n) {
+    if (!s || (n && !bytes)) return MKT_E_ARG;
+    if (s->done) return rfail(s, MKT_E_STATE, "add after run");
+    RCHK(s, hipSetDevice(s->device));
+    if (s->len + n + 1 > s->cap) {
+        size_t ncap = s->cap ? s->cap : ((size_t)256 << 20);
+        while (ncap < s->len + n + 1) ncap *= 2;
+        uint8_t* nb = nullptr;
+        RCHK(s, hipMalloc((void**)&nb, ncap + 64));
+        if (s->d_text) { if (s->len) RCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice)); RCHK(s, hipFree(s->d_text)); }
+        s->d_text = nb; s->cap = ncap;
+    }
+    if (n) RCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes, n, hipMemcpyHostToDevice, s->stream));
+    RCHK(s, hipStreamSynchronize(s->stream));
+    s->len += n;
+    return MKT_OK;
+}
+
+/* hskip / keylen as krmdup's -k -K -s -S (krmdup.cpp:229-262).  interleaved != 0: ONE output (read 1 and read 2 records alternating,
+ * krmdup.pipe), else two.  stats: total, uniq, dup, discard (krmdup.cpp:377-390). */
+int mkt_rmdup_run(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved, uint64_t stats[4], uint64_t out_bytes[2]) {
+    if (!s || !stats || !out_bytes) return MKT_E_ARG;
+    if (keylen1 + keylen2 > 32 || keylen1 + keylen2 < 16) return rfail(s, MKT_E_ARG, "invalid key sizes (krmdup.cpp:258)");
+    RCHK(s, hipSetDevice(s->device));
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    out_bytes[0] = out_bytes[1] = 0;
+    s->done = true;
+    if (s->len == 0) return MKT_OK;
+    {   // getline semantics: a missing final newline ends the last line all the same
+        char last = 0;
+        RCHK(s, hipMemcpy(&last, s->d_text + s->len - 1, 1, hipMemcpyDeviceToHost));
+        if (last != '\n') { const char nlc = '\n'; RCHK(s, hipMemcpy(s->d_text + s->len, &nlc, 1, hipMemcpyHostToDevice)); ++s->len; }
+    }
+    const uint64_t n = s->len;
+    hipStream_t st = s->stream;
+    std::vector<void*> owned;
+    auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
+#define RALLOC(ptr, bytes_) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes_)); if (e_ != hipSuccess) { cleanup(); return rfail(s, MKT_E_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(bytes_), hipGetErrorString(e_)); } owned.push_back((void*)(ptr)); } while (0)
+#define RRUN(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return rfail(s, MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    const uint32_t chunks = (uint32_t)((n + SCHUNK - 1) / SCHUNK);
+    uint64_t* d_cnt = nullptr;
+    RALLOC(d_cnt, ((size_t)chunks + 2) * sizeof(uint64_t));
+    hipLaunchKernelGGL(k_nl_count, dim3(chunks), dim3(SWG), 0, st, (const uint8_t*)s->d_text, n, d_cnt);
+    RRUN(launch_exscan(d_cnt, chunks, d_cnt + chunks, st));
+    uint64_t nl = 0;
+    RRUN(hipMemcpyAsync(&nl, d_cnt + chunks, sizeof nl, hipMemcpyDeviceToHost, st));
+    RRUN(hipStreamSynchronize(st));
+    const uint64_t npairs = nl / 8;                          // a truncated last record is ignored (undefined in the reference)
+    if (npairs >= (1ull << 32)) { cleanup(); return rfail(s, MKT_E_ARG, "%llu pairs: indexed with 32 bits", (unsigned long long)npairs); }
+    if (npairs == 0) { cleanup(); return MKT_OK; }
+    uint64_t* d_starts = nullptr;
+    SortRec *rA = nullptr, *rB = nullptr;
+    uint8_t* d_state = nullptr;
+    uint32_t *d_hist = nullptr, *d_bcnt = nullptr, *d_order = nullptr;
+    unsigned long long* d_counts = nullptr;
+    uint64_t* d_base = nullptr;
+    const uint32_t nbatch = (uint32_t)((npairs + RM_BATCH - 1) / RM_BATCH);
+    RALLOC(d_starts, (nl + 2) * sizeof(uint64_t));
+    RALLOC(rA, (npairs + 1) * sizeof(SortRec));
+    RALLOC(rB, (npairs + 1) * sizeof(SortRec));
+    RALLOC(d_state, npairs + 64);
+    RALLOC(d_hist, (size_t)16 * 1024 * 4 + 256);
+    RALLOC(d_bcnt, (size_t)nbatch * 4 * sizeof(uint32_t));
+    RALLOC(d_base, (size_t)nbatch * 4 * sizeof(uint64_t));
+    RALLOC(d_order, (npairs + 1) * sizeof(uint32_t));
+    RALLOC(d_counts, 64);
+    RRUN(hipMemsetAsync(d_counts, 0, 64, st));
+    hipLaunchKernelGGL(k_nl_starts, dim3(chunks), dim3(SWG), 0, st, (const uint8_t*)s->d_text, n, (const uint64_t*)d_cnt, d_starts);
+    RmParams P;
+    P.hskip1 = hskip1; P.epos1 = hskip1 + keylen1; P.hskip2 = hskip2; P.epos2 = hskip2 + keylen2;
+    const unsigned pgrid = (unsigned)((npairs + 255) / 256);
+    hipLaunchKernelGGL(k_rm_keys, dim3(pgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, npairs, P, rA);
+    uint32_t G = (uint32_t)((npairs + 8191) / 8192);
+    if (G > 1024) G = 1024;
+    if (G == 0) G = 1;
+    const uint64_t per = (npairs + G - 1) / G;
+    auto pass = [&](int which, int shift) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, npairs, per, which, shift, d_hist, G);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(SWG), 0, st, d_hist, 16u * G);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, npairs, per, which, shift, (const uint32_t*)d_hist, G, rB);
+        std::swap(rA, rB);
+    };
+    for (int sh = 0; sh < 64; sh += 4) pass(1, sh);          // the key ...
+    pass(0, 0);                                               // ... then the bucket (one set per bucket, krmdup.cpp:325)
+    hipLaunchKernelGGL(k_rm_mark, dim3(pgrid), dim3(256), 0, st, (const SortRec*)rA, npairs, d_state, d_counts);
+    hipLaunchKernelGGL(k_rm_order, dim3(nbatch), dim3(SWG), 0, st, (const uint8_t*)d_state, npairs, (const uint64_t*)d_base, d_bcnt, d_order, 0);
+    std::vector<uint32_t> bc((size_t)nbatch * 4);
+    unsigned long long hc[3] = {0, 0, 0};
+    RRUN(hipMemcpyAsync(bc.data(), d_bcnt, bc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    RRUN(hipMemcpyAsync(hc, d_counts, sizeof hc, hipMemcpyDeviceToHost, st));
+    RRUN(hipStreamSynchronize(st));
+    std::vector<uint64_t> base(bc.size());
+    uint64_t nkept = 0;
+    for (size_t k = 0; k < bc.size(); ++k) { base[k] = nkept; nkept += bc[k]; }
+    stats[1] = hc[0]; stats[2] = hc[1]; stats[3] = hc[2]; stats[0] = hc[0] + hc[1] + hc[2];
+    if (nkept != hc[0]) { cleanup(); return rfail(s, MKT_E_KERNEL, "kept %llu pairs but counted %llu unique ones", (unsigned long long)nkept, hc[0]); }
+    if (nkept) {
+        RRUN(hipMemcpyAsync(d_base, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_rm_order, dim3(nbatch), dim3(SWG), 0, st, (const uint8_t*)d_state, npairs, (const uint64_t*)d_base, d_bcnt, d_order, 1);
+        const uint32_t wg = (uint32_t)((nkept + RPW - 1) / RPW);
+        uint64_t* d_wsum = nullptr;
+        RALLOC(d_wsum, ((size_t)wg + 2) * sizeof(uint64_t));
+        for (int which = interleaved ? 2 : 0; which < (interleaved ? 3 : 2); ++which) {
+            hipLaunchKernelGGL(k_rm_sums, dim3(wg), dim3(SWG), 0, st, (const uint32_t*)d_order, nkept, (const uint64_t*)d_starts, which, d_wsum);
+            RRUN(launch_exscan(d_wsum, wg, d_wsum + wg, st));
+            uint64_t total = 0;
+            RRUN(hipMemcpyAsync(&total, d_wsum + wg, sizeof total, hipMemcpyDeviceToHost, st));
+            RRUN(hipStreamSynchronize(st));
+            const int slot = interleaved ? 0 : which;
+            if (s->d_out[slot]) { (void)hipFree(s->d_out[slot]); s->d_out[slot] = nullptr; }
+            { hipError_t e_ = hipMalloc((void**)&s->d_out[slot], total + 64); if (e_ != hipSuccess) { cleanup(); return rfail(s, MKT_E_NOMEM, "hipMalloc of the output failed: %s", hipGetErrorString(e_)); } }
+            hipLaunchKernelGGL(k_rm_copy, dim3(wg), dim3(SWG), 0, st, (const uint32_t*)d_order, nkept, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, which, (const uint64_t*)d_wsum, s->d_out[slot]);
+            RRUN(hipGetLastError());
+            RRUN(hipStreamSynchronize(st));
+            s->out_len[slot] = total;
+            out_bytes[slot] = total;
+        }
+    }
+    cleanup();
+#undef RALLOC
+#undef RRUN
+    return MKT_OK;
+}
+
+/* output `which` (0: read 1 or the interleaved stream, 1: read 2), bytes [off, off + n) */
+int mkt_rmdup_fetch(mkt_rmdup* s, int which, uint64_t off, char* out, size_t n) {
+    if (!s || which < 0 || which > 1 || (n && !out)) return MKT_E_ARG;
+    if (!s->done) return rfail(s, MKT_E_STATE, "fetch before run");
+    if (off + n > s->out_len[which]) return rfail(s, MKT_E_ARG, "range past the end of the output");
+    RCHK(s, hipSetDevice(s->device));
+    if (n) RCHK(s, hipMemcpy(out, s->d_out[which] + off, n, hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""SURVEY.md 8(f) N2 on the GPU: mkt_rmdup_* and the bin/krmdup / bin/krmdup.pipe drop-ins against the golden vectors made by
+the reference itself (tests/golden/krmdup_golden.json), against the oracle restatement and -- when the build travelled -- against
+oracle/_ref/krmdup.ref run on the same input.  Bit-exact: read files byte for byte, log byte for byte."""
+import json
+import os
+
+import pytest
+
+import microcket_amd as m
+import util
+from test_krmdup import _case_input, _golden, _kw
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rmdup_matches_reference_goldens():
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    for c in _golden()["cases"]:
+        text = _case_input(c)
+        kw = _kw(c["args"])
+        r1, r2, st = m.rmdup(text, **kw)
+        assert util.krmdup_log(*st).decode() == c["log"], c["name"]
+        assert util.sha(r1) == c["read1_sha256"] and util.sha(r2) == c["read2_sha256"], c["name"]
+        inter, _none, st2 = m.rmdup(text, interleaved=True, **kw)
+        assert st2 == st and _none == b""
+        assert util.sha(b"\n".join(util.fastq_records(inter))) == c["pipe_records_sha256"], c["name"]
+
+
+def test_rmdup_edge_inputs_vs_oracle():
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    base = util.synth_fastq(51, 300, 40)
+    for text in (b"", base, base[:-1], util.synth_fastq(52, 70000, 30, dup_rate=0.8), util.synth_fastq(53, 2000, 21, short_rate=0.5),
+                 b"@a\nNNNNNNNNNNNNNNNNNNNNNNNNNNNNNN\n+\nFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF\n@a\nACGTACGTACGTACGTACGTACGTACGTAC\n+\nFFFFFFFFFFFFFFFFFFFFFFFFFFFFFF\n"):
+        o1, o2, ol = util.krmdup_oracle(text)
+        r1, r2, st = m.rmdup(text, piece=100003)
+        assert (r1, r2, util.krmdup_log(*st)) == (o1, o2, ol), len(text)
+
+
+def test_krmdup_executables_are_drop_ins():
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    exe = os.path.join(os.path.dirname(m.exe_path()), "krmdup")
+    text = util.synth_fastq(61, 8000, 70)
+    for args in ((), ("-k", "2", "-K", "4", "-s", "10", "-S", "14")):
+        o1, o2, ol = util.krmdup_oracle(text, **_kw(args))
+        rc, r1, r2, log, err = util.krmdup_run_cli(exe, text, False, args)
+        assert rc == 0, err
+        assert (r1, r2, log) == (o1, o2, ol)
+        rc, so, _, log, err = util.krmdup_run_cli(exe + ".pipe", text, True, args)
+        assert rc == 0 and log == ol, err
+        l1, l2 = o1.split(b"\n")[:-1], o2.split(b"\n")[:-1]
+        assert so == b"".join(b"\n".join(l1[i:i + 4] + l2[i:i + 4]) + b"\n" for i in range(0, len(l1), 4))
+        if os.path.exists(util.KRMDUP_REF):
+            rrc, q1, q2, qlog, qerr = util.krmdup_run_cli(util.KRMDUP_REF, text, False, args)
+            assert (rrc, q1, q2, qlog) == (0, r1, r2, log)
+    # exit codes of the reference: usage 2, key sizes 1
+    import subprocess
+    assert subprocess.run([exe], stderr=subprocess.PIPE).returncode == 2
+    assert subprocess.run([exe, "-i", "x", "-o", "y", "-s", "3", "-S", "3"], stderr=subprocess.PIPE).returncode == 1

@@ -336,3 +336,87 @@ class _FakeRank:
             tot += x
         t.copy_(tot)
         self.fd.bar.wait()
+
+
+# ---- krmdup: FASTQ generator, oracle binding, reference runner ----------------------------------------
+KRMDUP_REF = os.path.join(ROOT, "oracle", "_ref", "krmdup.ref")
+KRMDUP_PIPE_REF = os.path.join(ROOT, "oracle", "_ref", "krmdup.pipe.ref")
+
+
+def synth_fastq(seed, pairs, read_len=100, dup_rate=0.3, n_rate=0.02, short_rate=0.02, lower_rate=0.01) -> bytes:
+    """Seeded interleaved paired-end FASTQ (8 lines per pair): PCR-duplicate-like repeats of earlier fragments (same leading
+    bases, different read names and tails), some N bases inside and outside the key window, reads shorter than the key
+    window, a few lower-case bases (the reference folds case in the key but not in the bucket letter)."""
+    import random
+    rnd = random.Random(seed)
+    frags = []
+    out = []
+    for i in range(pairs):
+        if frags and rnd.random() < dup_rate:
+            a, b = frags[rnd.randrange(len(frags))]
+            a = a[:40] + "".join(rnd.choice("ACGT") for _ in range(len(a) - 40)) if len(a) > 40 else a      # same key window, other tail
+        else:
+            la = read_len if rnd.random() > short_rate else rnd.randrange(3, 24)
+            lb = read_len if rnd.random() > short_rate else rnd.randrange(3, 24)
+            a = "".join(rnd.choice("ACGT") for _ in range(la))
+            b = "".join(rnd.choice("ACGT") for _ in range(lb))
+            if rnd.random() < n_rate:
+                k = rnd.randrange(len(a)); a = a[:k] + "N" + a[k + 1:]
+            if rnd.random() < n_rate:
+                k = rnd.randrange(min(len(b), 30)); b = b[:k] + "N" + b[k + 1:]
+            if rnd.random() < lower_rate:
+                k = rnd.randrange(min(len(a), 22)); a = a[:k] + a[k].lower() + a[k + 1:]
+            frags.append((a, b))
+        out.append(f"@R{seed}.{i} 1:N:0\n{a}\n+{'' if i % 3 else 'R' + str(i)}\n{'F' * len(a)}\n@R{seed}.{i} 2:N:0\n{b}\n+\n{'#' * len(b)}\n")
+    return "".join(out).encode()
+
+
+class KStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("total", "uniq", "dup", "discard")]
+
+
+class _KP(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("hskip1", "keylen1", "hskip2", "keylen2")]
+
+
+def krmdup_oracle(text: bytes, hskip1=5, keylen1=16, hskip2=5, keylen2=16):
+    """The CPU restatement (oracle/krmdup_oracle.c): (read1 bytes, read2 bytes, log text)."""
+    global _oracle
+    ensure_built()
+    if _oracle is None:
+        _oracle = C.CDLL(ORACLE_SO)
+    a, b, st = _OB(), _OB(), KStats()
+    kp = _KP(hskip1, keylen1, hskip2, keylen2)
+    rc = _oracle.krm_run(text, C.c_size_t(len(text)), C.byref(kp), C.byref(a), C.byref(b), C.byref(st))
+    assert rc == 0
+    r1 = C.string_at(a.p, a.n) if a.n else b""
+    r2 = C.string_at(b.p, b.n) if b.n else b""
+    _oracle.krm_buf_free(C.byref(a))
+    _oracle.krm_buf_free(C.byref(b))
+    return r1, r2, krmdup_log(st.total, st.uniq, st.dup, st.discard)
+
+
+def krmdup_log(total, uniq, dup, discard) -> bytes:
+    return f"Total\t{total}\nUniq\t{uniq}\nDup\t{dup}\nDiscard\t{discard}\n".encode()
+
+
+def krmdup_run_cli(exe, text, pipe=False, args=()):
+    """Runs a krmdup executable (the reference build or the GPU one): (rc, read1, read2 | stdout, log, stderr)."""
+    with tempfile.TemporaryDirectory(prefix="krm_") as d:
+        inp = os.path.join(d, "in.fq")
+        with open(inp, "wb") as f:
+            f.write(text)
+        pre = os.path.join(d, "o")
+        p = subprocess.run([exe, "-i", inp, "-o", pre, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        rd = lambda fn: open(fn, "rb").read() if os.path.exists(fn) else b""
+        if pipe:
+            return p.returncode, p.stdout, b"", rd(pre + ".log"), p.stderr
+        return p.returncode, rd(pre + ".read1.fq"), rd(pre + ".read2.fq"), rd(pre + ".log"), p.stderr
+
+
+def fastq_records(b: bytes):
+    """sorted list of 4-line records (canonical form of krmdup.pipe's stdout, whose bucket order is schedule dependent)"""
+    L = b.split(b"\n")
+    if L and L[-1] == b"":
+        L.pop()
+    return sorted(b"\n".join(L[i:i + 8]) for i in range(0, len(L), 8))
