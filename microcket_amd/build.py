@@ -114,6 +114,18 @@ def build_krmdup(force=False):
     return KRMDUP
 
 
+MAKESTAT = os.path.join(HERE, "bin", "makestat")
+
+
+def build_makestat(force=False):
+    """bin/makestat: native stand-in for the reference's bin/make.stat.pl; host-only, no GPU library."""
+    src = os.path.join(CSRC, "makestat_main.cpp")
+    if force or _newer(MAKESTAT, [src]):
+        os.makedirs(os.path.dirname(MAKESTAT), exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", MAKESTAT])
+    return MAKESTAT
+
+
 def build_oracle():
     """Test infrastructure: CPU restatement (+ the reference itself when /root/reference is present)."""
     _run(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
@@ -139,6 +151,7 @@ def build_all(force=False, extras=True):
     build_exe(force)
     build_pairsort(force)
     build_krmdup(force)
+    build_makestat(force)
     if extras:
         build_oracle()
         build_test_tools()
