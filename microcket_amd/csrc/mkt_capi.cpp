@@ -57,6 +57,7 @@ struct mkt_ctx {
     // host (pinned)
     size_t h_len = 0;                   // bytes in the input slot being filled
     BlockResult* h_res = nullptr; size_t res_slots = 0, res_used = 0, res_folded = 0;
+    std::vector<const uint8_t*> res_text; std::vector<size_t> res_n;      // resident path: the text of every queued block (a failed one is re-run)
     // ---- streaming pipeline (mkt_submit / mkt_input_window): the caller fills pinned input slots and queues GPU work
     // without waiting; one worker thread takes the results in order, copies the outputs back and hands them to the
     // consumer (mkt_drain / mkt_drain_wait).  reader || H2D || kernels || D2H || writer all overlap.
@@ -863,6 +864,8 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
     const int cfg_used = c->cfg;
     int rc = enqueue_block(c, (const uint8_t*)d_text, n, cfg_used, c->res_used);
     if (rc) return rc;
+    if (c->res_text.size() < c->res_slots) { c->res_text.resize(c->res_slots); c->res_n.resize(c->res_slots); }
+    c->res_text[c->res_used] = (const uint8_t*)d_text; c->res_n[c->res_used] = n;
     ++c->res_used;
     c->last_n = n; c->last_cfg = cfg_used; c->last_text = (const uint8_t*)d_text;
     c->bytes_in += n;
@@ -881,20 +884,31 @@ int mkt_sync(mkt_ctx* c) {
     fold_timing(c);
     const double t2 = dbg ? now() : 0;
     int rc = MKT_OK;
-    // A probe block (the only one in flight) whose line table overflowed is run again with the next smaller geometry:
-    // its text is still there and a failed block leaves the run totals alone.  Later blocks are not retried.
-    while (c->probing && c->res_used == 1 && c->res_folded == 0 && (c->h_res[0].err & (E_LINE_TABLE | E_OVF_SLOTS)) &&
-           c->p.tiles == MKT_TILES_AUTO && c->cfg != CFG_SMALL && c->last_text) {
-        c->cfg = c->cfg == CFG_FAST ? CFG_MID : (c->cfg == CFG_MID ? CFG_DENSE : CFG_SMALL);
-        c->last_cfg = c->cfg;
-        if ((rc = enqueue_block(c, c->last_text, c->last_n, c->cfg, 0))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        fold_timing(c);
-    }
+    // A block whose line table overflowed (shorter lines than the geometry was chosen for: the first block of an input, or
+    // a stream whose read length shrinks on the way) is run again with the next smaller geometry -- together with every
+    // block queued behind it, which ran on top of run totals the failed block never advanced.  The texts are still resident.
     bool changed = false;
+    int replays = 0;
     for (size_t k = c->res_folded; k < c->res_used; ++k) {
         const BlockResult& r = c->h_res[k];
-        if (r.err) { rc = check_result(c, r); break; }      // fail loudly
+        if (r.err) {
+            if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && c->p.tiles == MKT_TILES_AUTO && c->cfg != CFG_SMALL && replays < 4 && c->res_text.size() > k) {
+                ++replays;
+                c->cfg = c->cfg == CFG_FAST ? CFG_MID : (c->cfg == CFG_MID ? CFG_DENSE : CFG_SMALL);
+                c->last_cfg = c->cfg;
+                changed = true;
+                DevRun dr;
+                dr.groups = c->acc.groups; dr.sc = c->acc.sc; dr.emitted = c->acc.emitted;
+                HIPCHK(c, hipMemcpy(c->d_run, &dr, sizeof dr, hipMemcpyHostToDevice));
+                for (size_t j = k; j < c->res_used; ++j) if ((rc = enqueue_block(c, c->res_text[j], c->res_n[j], c->cfg, j))) return rc;
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                fold_timing(c);
+                --k;                                     // look at the same block again
+                continue;
+            }
+            rc = check_result(c, r);                     // fail loudly
+            break;
+        }
         c->acc.add_block(r); c->tiles_total += r.tiles; c->tiles_deferred += r.pad;
         changed = adapt_geometry(c, r) || changed;
         c->sc_unfolded += r.sc; c->emitted_unfolded += r.emitted;

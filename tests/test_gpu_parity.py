@@ -203,6 +203,30 @@ def test_resident_path_multi_block_and_q2_across_batches():
         assert 0 < tm.deferred_tiles < tm.tiles // 3, (tm.tiles, tm.deferred_tiles)
 
 
+def test_resident_path_replays_a_block_when_the_lines_get_shorter():
+    """Concatenated lanes of different read length: 150 bp blocks (48 KiB tiles) followed, in the same run and without a sync in
+    between, by 50 bp blocks whose lines overflow the line table.  The failing block and everything queued behind it are
+    re-run with the next smaller geometry (mkt_sync); log and counts must equal the oracle's on the concatenated text."""
+    _need_gpu()
+    with m.Context("unc", 0.5, 10, False, 4, device=0) as c:
+        a = c.dataset(1234, 0, 60000, 1 << 14, read_len=150, tail_group=False)
+        blocks = list(a.blocks)
+        host = b"".join(c.copy_to_host(p, nb) for (p, nb, g) in a.blocks)
+        with m.Context("unc", 0.5, 10, False, 4, device=0) as c2:          # the second data set lives in another context's arena
+            b = c2.dataset(1235, 0, 50000, 1 << 14, first_group=60000, read_len=50, tail_group=True)
+            host += b"".join(c2.copy_to_host(p, nb) for (p, nb, g) in b.blocks)
+            for (p, nb, g) in blocks + list(b.blocks):
+                c.submit_device(p, nb)
+            st = c.finish(True)
+            tm = c.timing()
+            b.close()
+        a.close()
+    po, so, lo, ost = util.oracle_run(host, "unc", 4, 0.5, 10, False)
+    assert c.format_log(st) == lo
+    assert st.groups == ost.groups and st.pairs == ost.pairs and st.pair_bytes == len(po)
+    assert tm.tiles > 0
+
+
 def test_two_contexts_as_two_shards():
     """The sharded bookkeeping (group offsets, Q1 on the last shard only) with real kernels: 2 contexts on one GPU."""
     _need_gpu()
