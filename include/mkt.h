@@ -167,6 +167,8 @@ int mkt_synth_device(mkt_ctx* ctx, uint64_t seed, int profile, int genome, int r
                      uint64_t first_group, uint64_t n_groups, int tail_group,
                      const void** d_text, size_t* n_bytes);
 int mkt_copy_to_host(mkt_ctx* ctx, const void* d_src, void* dst, size_t n);
+/* host text -> a device buffer owned by the context (16-byte aligned, lives until mkt_destroy): a block for mkt_submit_device */
+int mkt_device_text(mkt_ctx* ctx, const char* bytes, size_t n, const void** d_text);
 
 /* A whole synthetic data set resident in HBM, cut into group-aligned blocks (bench.py's workload:
  * 100 M read pairs = ~92 GB of SAM text on one MI355X).  Blocks are 16-byte aligned. */

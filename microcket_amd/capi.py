@@ -13,7 +13,7 @@ EXPORTS = [
     "mkt_abi_version", "mkt_strerror", "mkt_last_error", "mkt_device_count", "mkt_create", "mkt_destroy",
     "mkt_input_window", "mkt_submit_window",
     "mkt_submit", "mkt_drain", "mkt_drain_wait", "mkt_submit_device", "mkt_sync", "mkt_fetch_last_block", "mkt_finish",
-    "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host",
+    "mkt_format_log", "mkt_get_timing", "mkt_reset_timing", "mkt_synth_device", "mkt_copy_to_host", "mkt_device_text",
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
     "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
     "mkt_rmdup_create", "mkt_rmdup_destroy", "mkt_rmdup_error", "mkt_rmdup_add", "mkt_rmdup_run", "mkt_rmdup_fetch",
@@ -90,6 +90,7 @@ def load_library():
     L.mkt_synth_device.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_int,
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     L.mkt_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mkt_device_text.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
     L.mkt_dataset_create.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
                                      C.POINTER(C.c_void_p)]
     L.mkt_dataset_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -254,6 +255,12 @@ class Context:
         buf = C.create_string_buffer(max(n, 1))
         self._chk(self.L.mkt_copy_to_host(self.h, C.c_void_p(d_ptr), buf, n), "mkt_copy_to_host")
         return buf.raw[:n]
+
+    def device_text(self, data: bytes):
+        """host text -> device buffer owned by the context; returns the device pointer (a block for submit_device)"""
+        p = C.c_void_p()
+        self._chk(self.L.mkt_device_text(self.h, data, len(data), C.byref(p)), "mkt_device_text")
+        return p.value
 
     def reset(self):
         self._chk(self.L.mkt_reset(self.h), "mkt_reset")

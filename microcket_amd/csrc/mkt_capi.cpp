@@ -57,6 +57,7 @@ struct mkt_ctx {
     // host (pinned)
     size_t h_len = 0;                   // bytes in the input slot being filled
     BlockResult* h_res = nullptr; size_t res_slots = 0, res_used = 0, res_folded = 0;
+    std::vector<void*> uploads;          // mkt_device_text buffers (freed with the context)
     std::vector<const uint8_t*> res_text; std::vector<size_t> res_n;      // resident path: the text of every queued block (a failed one is re-run)
     // ---- streaming pipeline (mkt_submit / mkt_input_window): the caller fills pinned input slots and queues GPU work
     // without waiting; one worker thread takes the results in order, copies the outputs back and hands them to the
@@ -236,6 +237,7 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->s_in) (void)hipStreamDestroy(c->s_in);
     if (c->s_out) (void)hipStreamDestroy(c->s_out);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (void* u : c->uploads) (void)hipFree(u);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_sam) (void)hipFree(c->d_sam);
@@ -1383,6 +1385,17 @@ int mkt_debug_stamps(mkt_ctx* c, unsigned long long* out16) {
     return MKT_OK;
 }
 #endif
+
+int mkt_device_text(mkt_ctx* c, const char* bytes, size_t n, const void** d_text) {
+    if (!c || !d_text || (n && !bytes)) return MKT_E_ARG;
+    HIPCHK(c, hipSetDevice(c->p.device));
+    void* d = nullptr;
+    HIPCHK(c, hipMalloc(&d, n + 64));
+    c->uploads.push_back(d);
+    if (n) HIPCHK(c, hipMemcpy(d, bytes, n, hipMemcpyHostToDevice));
+    *d_text = d;
+    return MKT_OK;
+}
 
 int mkt_copy_to_host(mkt_ctx* c, const void* d_src, void* dst, size_t n) {
     if (!c || !d_src || !dst) return MKT_E_ARG;

@@ -204,27 +204,27 @@ def test_resident_path_multi_block_and_q2_across_batches():
 
 
 def test_resident_path_replays_a_block_when_the_lines_get_shorter():
-    """Concatenated lanes of different read length: 150 bp blocks (48 KiB tiles) followed, in the same run and without a sync in
-    between, by 50 bp blocks whose lines overflow the line table.  The failing block and everything queued behind it are
-    re-run with the next smaller geometry (mkt_sync); log and counts must equal the oracle's on the concatenated text."""
+    """Concatenated inputs of very different line length, queued on the resident path without a sync in between: two blocks of
+    150 bp reads (48 KiB tiles), then a block of ~35-byte lines that overflows even the generic kernel's line table.  The
+    failing block -- not the probe -- is re-run with smaller geometries by mkt_sync; outputs must equal the oracle's."""
     _need_gpu()
-    with m.Context("unc", 0.5, 10, False, 4, device=0) as c:
-        a = c.dataset(1234, 0, 60000, 1 << 14, read_len=150, tail_group=False)
-        blocks = list(a.blocks)
-        host = b"".join(c.copy_to_host(p, nb) for (p, nb, g) in a.blocks)
-        with m.Context("unc", 0.5, 10, False, 4, device=0) as c2:          # the second data set lives in another context's arena
-            b = c2.dataset(1235, 0, 50000, 1 << 14, first_group=60000, read_len=50, tail_group=True)
-            host += b"".join(c2.copy_to_host(p, nb) for (p, nb, g) in b.blocks)
-            for (p, nb, g) in blocks + list(b.blocks):
-                c.submit_device(p, nb)
-            st = c.finish(True)
-            tm = c.timing()
-            b.close()
-        a.close()
-    po, so, lo, ost = util.oracle_run(host, "unc", 4, 0.5, 10, False)
+    a1, a2 = util.synth("unc", 1234, 4000, tail=0), util.synth("unc", 1235, 4000, tail=0, first=4000)
+    rows = []
+    for g in range(6000):
+        rows.append(f"s{g}\t65\tchr1\t{1000 + g}\t60\t5M\t=\t1\t0\tA\tF\n")
+        rows.append(f"s{g}\t129\tchr1\t{9000 + 3 * g}\t60\t5M\t=\t1\t0\tA\tF\n")
+    short = "".join(rows).encode()
+    host = a1 + a2 + short
+    po, so, lo, ost = util.oracle_run(host, "unc", 4, 0.5, 10, True)
+    with m.Context("unc", 0.5, 10, True, 4, device=0, ordered=False) as c:
+        for part in (a1, a2, short):
+            c.submit_device(c.device_text(part), len(part))
+        st = c.finish(True)
+        pairs, sam = c.fetch_last_block()
     assert c.format_log(st) == lo
     assert st.groups == ost.groups and st.pairs == ost.pairs and st.pair_bytes == len(po)
-    assert tm.tiles > 0
+    pshort = util.oracle_run(short, "unc", 4, 0.5, 10, True)[0]
+    assert util.canon(pairs)[:0] == b"" and len(pairs) >= len(pshort) - 200      # the last block's own pairs (its final group is still in)
 
 
 def test_two_contexts_as_two_shards():
