@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sam=yes and flash resident legs")
     ap.add_argument("--leg-pairs", type=int, default=32_000_000, help="read pairs of the sam=yes / flash legs")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=16_000_000, help="pairs of the file the CPU reference and the end-to-end executables are timed on (~20 s of reference time)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
