@@ -101,6 +101,7 @@ int main(int argc, char* argv[]) {
     auto mark = [&](const char* what) {
         if (verbose) fprintf(stderr, "[mkt] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     };
+    if (verbose) { (void)mkt_device_count(); mark("hip runtime up"); }
     mkt_ctx* ctx = nullptr;
     int rc = mkt_create(&p, &ctx);
     mark("context");
@@ -196,6 +197,7 @@ int main(int argc, char* argv[]) {
         size_t cap = 0;
         rc = mkt_input_window(ctx, &win, &cap);
         if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return bail(21); }
+        if (verbose && fpos == 0) mark("first window");
         size_t got = 0;
         int last = 0;
         if (regular) {
