@@ -416,7 +416,7 @@ static void fold_timing(mkt_ctx* c) {       // stream must be idle
 // Stream idle: make room for `need` entries, keeping the c->acc.sc entries already there.
 static int ensure_sc_list(mkt_ctx* c, size_t need) {
     if (need <= c->sc_cap) return MKT_OK;
-    size_t ncap = c->sc_cap ? c->sc_cap : ((size_t)1 << 25);       // 32 Mi entries (256 MiB) to start with
+    size_t ncap = c->sc_cap ? c->sc_cap : ((size_t)1 << 20);       // 1 Mi entries (8 MiB) at least; the resident path asks for its first 2 GB block's worth at once
     while (ncap < need) ncap *= 2;
     uint64_t* nl = nullptr;
     HIPCHK(c, hipMalloc((void**)&nl, ncap * sizeof(uint64_t)));

@@ -102,13 +102,26 @@ MKT_HD uint32_t digit_bits4(uint32_t w) {
     const uint32_t y = w & 0x7F7F7F7Fu;
     const uint32_t ge30 = (y + 0x50505050u) | w, ge3a = (y + 0x46464646u) | w;      // bit 7 of a byte: byte >= '0' / byte > '9'
     const uint32_t d = ge30 & ~ge3a & 0x80808080u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(d, 0x08040201u, 0u, false) >> 7;          // flags are 128 x {0, 1}: one dot product gathers them
+#else
     return (((d >> 7) * 0x00204081u) >> 21) & 0xFu;
+#endif
 }
 MKT_HD uint32_t ctz64(uint64_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__ffsll((long long)v) - 1u;
 #else
     return (uint32_t)__builtin_ctzll(v);
+#endif
+}
+
+// small products (line index x row pitch ...): the 24-bit multiplier is full rate, v_mul_lo_u32 is quarter rate
+MKT_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
 #endif
 }
 

@@ -152,7 +152,7 @@ MKT_HD uint32_t ws_bits16_ref(const uint8_t* win, uint32_t r0, uint32_t wlen) {
 template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t i, uint64_t& ws0, uint64_t& ws1) {
     const uint64_t* row = reinterpret_cast<const uint64_t*>(st.u.m.hmask[i]);
     const uint64_t A = row[0], B = row[1];
-    const uint32_t sh = (uint32_t)st.off16[i] - i * (uint32_t)Cfg::HSTRIDE;        // 0 (first line of a block) .. 16
+    const uint32_t sh = (uint32_t)st.off16[i] - mul24(i, (uint32_t)Cfg::HSTRIDE);  // 0 (first line of a block) .. 16
     ws0 = sh ? ((A >> sh) | (B << (64u - sh))) : A;
     ws1 = B >> sh;
 }
@@ -180,7 +180,7 @@ MKT_HD uint32_t nl_flags_exact(uint32_t x) {                      // 0x80 in eve
 template <class Cfg> MKT_HD uint32_t fast_row_start(const FastState<Cfg>& st, const TileGeom& G, uint32_t i, bool* multi) {
     *multi = false;
     if (i == 0u && G.w0 == 0u) return 0u;
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE]);
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE)]);
     const uint32_t f0 = nl_flags_exact(row[0]), f1 = nl_flags_exact(row[1]), f2 = nl_flags_exact(row[2]), f3 = nl_flags_exact(row[3]);
     // one bit per byte, byte order: flags sit at bit 7 of every byte, so dword j shifted right by (3 - j) interleaves them
     const uint32_t m = (f0 >> 3) | (f1 >> 2) | (f2 >> 1) | f3;    // byte b of dword j -> bit 8 b + 4 + j
@@ -195,7 +195,7 @@ template <class Cfg> MKT_HD uint32_t fast_row_start(const FastState<Cfg>& st, co
 template <class Cfg> MKT_HD uint32_t fast_line_len_in_head(const FastState<Cfg>& st, uint32_t i, uint32_t goff) {
     const uint32_t hv = st.hv16[i], hvn = st.hv16[i + 1u];
     if (hvn * 16u >= goff + 128u || hvn >= hv + (uint32_t)Cfg::HCH) return 0xFFFFu;
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE + 16u * (hvn - hv)]);
+    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + 16u * (hvn - hv)]);
     for (uint32_t d = 0; d < 4u; ++d) {
         uint32_t f = nl_flags_exact(row[d]);
         // the line's own leading newline sits in this very vector when hvn == hv: skip what lies in front of the line
@@ -214,7 +214,7 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     const uint32_t soff = fast_row_start(st, G, i, &multi);
     if (multi) st.abn = AB_SHORT_LINE;
     const uint32_t goff = 16u * (uint32_t)st.hv16[i] + soff;
-    const uint32_t off = i * (uint32_t)Cfg::HSTRIDE + soff;        // line start in the head store
+    const uint32_t off = mul24(i, (uint32_t)Cfg::HSTRIDE) + soff;  // line start in the head store
     st.goff[i] = (uint16_t)goff;
     st.off16[i] = (uint16_t)off;
     const uint32_t gl = G.w0 + goff;                               // ... and in the block
@@ -250,7 +250,7 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
         // same QNAME token as the line before: its first token must start at its first byte
         bool pm;
         const uint32_t psoff = fast_row_start(st, G, i - 1u, &pm);        // (its own lane sets off16[i - 1] in this same phase: recompute)
-        const uint32_t poff = (i - 1u) * (uint32_t)Cfg::HSTRIDE + psoff;
+        const uint32_t poff = mul24(i - 1u, (uint32_t)Cfg::HSTRIDE) + psoff;
         const uint32_t ql = r.qn_len;
         if (is_ws(tv.win[poff])) st.abn = AB_PREV_WS;
         else if (ql + 1u > (uint32_t)Cfg::HEADB - psoff) st.abn = AB_PREV_HEAD;          // beyond the previous line's head

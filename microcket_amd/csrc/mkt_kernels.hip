@@ -11,6 +11,7 @@
 //
 // No MFMA: this is byte/integer work bounded by HBM bandwidth (DESIGN.md has the byte budget).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "mkt_launch.h"
 
 // tile geometry of the fast configuration (the lean and the generic kernel must agree on TILE)
@@ -130,8 +131,13 @@ __device__ inline uint32_t ws_flags(uint32_t x) {                 // byte in {9.
     const uint32_t sp = ~((y ^ 0x20202020u) + 0x7F7F7F7Fu);       // == 32
     return (ctl | sp) & ~x & 0x80808080u;
 }
+// sixteen 0x80 byte flags (four dwords) -> one bit per byte.  v_dot4_u32_u8 does the gathering: the flags are 128 x {0, 1}, the
+// weights 1, 2, 4, 8 (16 .. 128 for the second dword), so two dot products per byte of result and one shift (the multiply-
+// gather of pack_msb costs a quarter-rate v_mul_lo_u32 per dword).
 __device__ inline uint32_t pack16(uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3) {
-    return pack_msb(f0) | (pack_msb(f1) << 4) | (pack_msb(f2) << 8) | (pack_msb(f3) << 12);
+    const uint32_t lo = __builtin_amdgcn_udot4(f1, 0x80402010u, __builtin_amdgcn_udot4(f0, 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(f3, 0x80402010u, __builtin_amdgcn_udot4(f2, 0x08040201u, 0u, false), false);
+    return (lo >> 7) | ((hi >> 7) << 8);
 }
 
 // Decoupled look-back on one descriptor word per tile.  Executed by one full wave.
@@ -536,45 +542,54 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         const uint32_t NL = st.NL;
         STAMP(2);
         STOP_AFTER(2)
-        // ---- line heads: the eight aligned 16-byte chunks from each line's first byte on (L2 hits: the bytes were
-        //      just streamed), with their whitespace bits
+        // ---- line heads: eight aligned 16-byte chunks per line, from the vector that holds the newline in front of it (the
+        //      fabric delivers most of them a second time), with their whitespace bits.  Only the block's last windows can
+        //      reach past the end of the text: every other tile takes the path without the per-lane end checks.
         {
             constexpr int HPT = (Cfg::LCAP * Cfg::HCH + NT - 1) / NT;      // chunks per lane
-            uint4 q[HPT];
+            auto heads = [&](auto edge_c) {
+                constexpr bool EDGE = decltype(edge_c)::value;
+                uint4 q[HPT];
 #pragma unroll
-            for (int k = 0; k < HPT; ++k) {                                // all loads first ...
-                const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
-                q[k] = make_uint4(0, 0, 0, 0);
-                if (it < NL * (uint32_t)Cfg::HCH) {
-                    const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
-                    const uint64_t g0 = (uint64_t)G.w0 + (((uint32_t)st.hv16[i] + c) << 4);
-                    if (g0 < n) q[k] = *reinterpret_cast<const uint4*>(a.text + g0);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < HPT; ++k) {                                // ... then the stores and the whitespace bits
-                const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
-                if (it >= NL * (uint32_t)Cfg::HCH) continue;
-                const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
-                const uint64_t g0 = (uint64_t)G.w0 + (((uint32_t)st.hv16[i] + c) << 4);
-                uint4 x = q[k];
-                if (g0 < n && g0 + 16u > n) {                              // last vector of the block: clear the bytes past the end
-                    const uint32_t keep = (uint32_t)(n - g0);              // 1..15
-                    uint32_t* w = reinterpret_cast<uint32_t*>(&x);
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const uint32_t lo = (uint32_t)d * 4u;
-                        w[d] = keep >= lo + 4u ? w[d] : (keep > lo ? (w[d] & ((1u << ((keep - lo) * 8u)) - 1u)) : 0u);
+                for (int k = 0; k < HPT; ++k) {                                // all loads first ...
+                    const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
+                    q[k] = make_uint4(0, 0, 0, 0);
+                    if (it < NL * (uint32_t)Cfg::HCH) {
+                        const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
+                        const uint32_t g0 = G.w0 + (((uint32_t)st.hv16[i] + c) << 4);       // < 2^31 + 64 Ki
+                        if (!EDGE || g0 < n) q[k] = *reinterpret_cast<const uint4*>(a.text + g0);
                     }
                 }
-                {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
-                    uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[i * (uint32_t)Cfg::HSTRIDE + (c << 4)]);
-                    row[0] = x.x; row[1] = x.y; row[2] = x.z; row[3] = x.w;
+#pragma unroll
+                for (int k = 0; k < HPT; ++k) {                                // ... then the stores and the whitespace bits
+                    const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
+                    if (it >= NL * (uint32_t)Cfg::HCH) continue;
+                    const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
+                    uint4 x = q[k];
+                    uint32_t keep = 16u;
+                    if (EDGE) {
+                        const uint32_t g0 = G.w0 + (((uint32_t)st.hv16[i] + c) << 4);
+                        keep = g0 >= n ? 0u : (n - g0 < 16u ? n - g0 : 16u);
+                        if (keep != 0u && keep < 16u) {                        // last vector of the block: clear the bytes past the end
+                            uint32_t* w = reinterpret_cast<uint32_t*>(&x);
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                const uint32_t lo = (uint32_t)d * 4u;
+                                w[d] = keep >= lo + 4u ? w[d] : (keep > lo ? (w[d] & ((1u << ((keep - lo) * 8u)) - 1u)) : 0u);
+                            }
+                        }
+                    }
+                    {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
+                        uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + (c << 4)]);
+                        row[0] = x.x; row[1] = x.y; row[2] = x.z; row[3] = x.w;
+                    }
+                    uint32_t m = pack16(ws_flags(x.x), ws_flags(x.y), ws_flags(x.z), ws_flags(x.w));
+                    if (EDGE && keep < 16u) m &= (1u << keep) - 1u;            // cleared bytes are not whitespace
+                    st.u.m.hmask[i][c] = (uint16_t)m;
                 }
-                uint32_t m = pack16(ws_flags(x.x), ws_flags(x.y), ws_flags(x.z), ws_flags(x.w));
-                if (g0 + 16u > n) m &= g0 < n ? (1u << (uint32_t)(n - g0)) - 1u : 0u;       // cleared bytes are not whitespace
-                st.u.m.hmask[i][c] = (uint16_t)m;
-            }
+            };
+            if ((uint64_t)G.w1 + 16u * ((uint32_t)Cfg::HCH + 2u) > (uint64_t)n) heads(std::true_type{});
+            else heads(std::false_type{});
         }
         __syncthreads();
         STOP_AFTER(9)
