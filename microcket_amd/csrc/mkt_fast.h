@@ -86,6 +86,9 @@ struct FastState {
     } u;
     // one bit per line of the window (ballots of the parse / start phases)
     uint64_t m_surv[4], m_eqp[4], m_r1[4], m_r2[4], m_start[4], m_emit[4];
+    // the tile's own group starts in line order: wave w of the start phase fills start_list[64 w, 64 w + start_cnt[w])
+    uint8_t start_list[256];
+    uint32_t start_cnt[4];
     // extension: this workgroup's cache of the chromosome table, kept across its tiles.  One word per entry (name bytes
     // in bits 0..47, table slot in 48..60, valid in 63), so that a lane never pairs one entry's name with another's slot
     uint64_t cc[64];

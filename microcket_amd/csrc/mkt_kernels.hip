@@ -635,9 +635,27 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             if (!st.abn && i >= first_idx && i < NLe && mask_bit(st.m_surv, i)) s0 = fast_is_start(st, tv, G, i);
             const uint64_t b = __ballot(s0);
             if ((tid & 63) == 0) st.m_start[ltid >> 6] = b;
+#if defined(MKT_GROUP1)
+            // the tile's own group starts, compacted in line order: the group phase then runs with full lanes on ONE wave
+            const bool own = s0 && i < end_idx;
+            const uint64_t bo = __ballot(own);
+            if (own) st.start_list[((ltid >> 6) << 6) + (uint32_t)__popcll(bo & ((1ull << (tid & 63)) - 1ull))] = (uint8_t)i;
+            if ((tid & 63) == 0) st.start_cnt[ltid >> 6] = (uint32_t)__popcll(bo);
+            if (i >= first_idx && i < end_idx) { st.u.g.g_info[i] = 0; st.u.g.g_plen[i] = 0; st.u.g.g_slen[i] = 0; }     // (the sums read every line of the tile)
+#endif
         }
         __syncthreads();
+#if defined(MKT_GROUP1)
+        const uint32_t sc0 = st.start_cnt[0], sc1 = sc0 + st.start_cnt[1], sc2 = sc1 + st.start_cnt[2], nst = sc2 + st.start_cnt[3];
+        auto start_line = [&](uint32_t L) -> uint32_t {
+            const uint32_t w = (L >= sc0 ? 1u : 0u) + (L >= sc1 ? 1u : 0u) + (L >= sc2 ? 1u : 0u);
+            const uint32_t base = w == 0u ? 0u : (w == 1u ? sc0 : (w == 2u ? sc1 : sc2));
+            return st.start_list[(w << 6) + (L - base)];
+        };
+        if (!st.abn && (tid >> 6) == 3) for (uint32_t L = (uint32_t)tid & 63u; L < nst; L += 64u) fast_group(st, tv, P, G, start_line(L));
+#else
         if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * MKT_RR) fast_group(st, tv, P, G, i);
+#endif
         __syncthreads();
         STAMP(4);
         STOP_AFTER(4)
@@ -698,10 +716,18 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         // ---- emit ----------------------------------------------------------------------------------
         const uint32_t total = st.sums.pair_bytes;
         uint8_t* const dst = s_out.pairs + st.base.pair_bytes;
+#if defined(MKT_GROUP1)
+        if ((tid >> 6) == 0) for (uint32_t L = (uint32_t)tid; L < nst; L += 64u) {
+            const uint32_t i = start_line(L);
+            fast_account(st, s_out, t, i);
+            fast_last(st, G, &a.tile_last[t], i);
+        }
+#else
         for (uint32_t i = first_idx + ltid; i < end_idx; i += NT) {
             fast_account(st, s_out, t, i);
             fast_last(st, G, &a.tile_last[t], i);
         }
+#endif
         // .pairs: one lane per reported pair writes its whole line (fast_emit_line)
         if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
             const auto& g = st.u.g;
