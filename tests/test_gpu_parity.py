@@ -223,8 +223,9 @@ def test_resident_path_replays_a_block_when_the_lines_get_shorter():
         pairs, sam = c.fetch_last_block()
     assert c.format_log(st) == lo
     assert st.groups == ost.groups and st.pairs == ost.pairs and st.pair_bytes == len(po)
+    # the last block's own outputs: the oracle's for that text plus the line of its final group (dropped by quirk Q1 in a whole run)
     pshort = util.oracle_run(short, "unc", 4, 0.5, 10, True)[0]
-    assert util.canon(pairs)[:0] == b"" and len(pairs) >= len(pshort) - 200      # the last block's own pairs (its final group is still in)
+    assert util.canon(pairs)[:len(util.canon(pshort))] == util.canon(pshort) or set(pshort.splitlines()) <= set(pairs.splitlines())
 
 
 def test_two_contexts_as_two_shards():
