@@ -378,7 +378,11 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
         HIPCHK(c, hipEventCreate(&e1));
         c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
     }
-    int grid = (int)(ntiles < 1024u ? ntiles : 1024u);
+#ifndef MKT_WPS
+#define MKT_WPS 4              // workgroups of the lean kernel per CU (mkt_kernels.hip compiles it for that many waves per SIMD)
+#endif
+    const uint32_t max_wgs = 256u * (uint32_t)MKT_WPS;      // 256 CUs: every workgroup resident, tiles dealt statically
+    int grid = (int)(ntiles < max_wgs ? ntiles : max_wgs);
     const bool lean = !c->p.ordered && cfg != CFG_SMALL && !c->no_lean;
     HIPCHK(c, hipEventRecord(e0, c->stream));
     if (lean) {
