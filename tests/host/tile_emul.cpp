@@ -258,8 +258,8 @@ int emul_finish(void* h, int drop_last, uint64_t group_offset, uint64_t total_gr
     // the dropped group's bytes are the tail of the (input-ordered) emulation output
     S.pairs.resize(s.pair_bytes);
     S.sam.resize(s.sam_bytes);
-    *out_pairs = (char*)malloc(S.pairs.size() + 1); memcpy(*out_pairs, S.pairs.data(), S.pairs.size()); *n_pairs = S.pairs.size();
-    *out_sam = (char*)malloc(S.sam.size() + 1); memcpy(*out_sam, S.sam.data(), S.sam.size()); *n_sam = S.sam.size();
+    *out_pairs = (char*)malloc(S.pairs.size() + 1); if (!S.pairs.empty()) memcpy(*out_pairs, S.pairs.data(), S.pairs.size()); *n_pairs = S.pairs.size();
+    *out_sam = (char*)malloc(S.sam.size() + 1); if (!S.sam.empty()) memcpy(*out_sam, S.sam.data(), S.sam.size()); *n_sam = S.sam.size();
     const int order[8] = {C_LOWMAP, C_MANYHITS, C_UNPAIRED, C_SELFCIRCLE, C_TRANS, C_CIS10K, C_CIS1K, C_CIS0};
     for (int k = 0; k < 8; ++k) counters8[k] = s.counters[order[k]];
     stats[0] = s.groups; stats[1] = s.pairs; stats[2] = S.err; stats[3] = S.blocks | (S.lean_tiles << 20) | (S.tiles << 42);
