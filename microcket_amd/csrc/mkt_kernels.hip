@@ -456,9 +456,17 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             if (v < nvp) xp[k] = *reinterpret_cast<const uint4*>(a.text + Gp.w0 + (v << 4));
         }
     };
-    if (PF > 0 && blockIdx.x < a.ntiles) prefetch(blockIdx.x);
+    if (PF > 0 && blockIdx.x < a.ntiles) prefetch(blockIdx.x);      // (experiment switch; assumes the default tile order)
     uint32_t rot = 0;
-    for (uint32_t t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+#if defined(MKT_XCD_MAP)
+    // Workgroups go to the 8 XCDs round-robin (blockIdx & 7), each XCD has its own L2: give the workgroups of one XCD CONSECUTIVE
+    // tiles, so that the halo a tile shares with its neighbour (6 of 54 KB) is fetched into that L2 once.
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t t_first = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+#else
+    const uint32_t t_first = blockIdx.x;
+#endif
+    for (uint32_t t = t_first; t < a.ntiles; t += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
         // (no barrier: the previous tile ended on one, and nothing below reads what lane 0 resets here before the barrier
@@ -480,6 +488,9 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
 #pragma unroll
             for (int k0 = 0; k0 < LPT; k0 += BATCH) {
                 uint4 x[BATCH];
+#if defined(MKT_SETPRIO)
+                __builtin_amdgcn_s_setprio(3);                 // the loads of a window go out ahead of other waves' arithmetic
+#endif
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
                     const uint32_t v = tid + (k0 + k) * NT;
@@ -488,6 +499,9 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                     // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
                     if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
+#if defined(MKT_SETPRIO)
+                __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {              // ... then the math
                     if (k0 + k >= LPT) continue;
