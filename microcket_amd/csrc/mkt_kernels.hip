@@ -458,6 +458,17 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
     };
     if (PF > 0 && blockIdx.x < a.ntiles) prefetch(blockIdx.x);      // (experiment switch; assumes the default tile order)
     uint32_t rot = 0;
+#ifndef MKT_TOUCH
+#define MKT_TOUCH 0          // 1 / 2 / 3: touch the NEXT tile's window (one dword per 128-byte line) before parse / groups / emit
+#endif
+    uint32_t touch0 = 0, touch1 = 0;
+    auto touch_next = [&](uint32_t tt) {     // pulls the next window towards this XCD's L2; nothing waits for these loads
+        if (tt >= a.ntiles) return;
+        const TileGeom Gp = fast_geom<Cfg>(tt, n);
+        const uint32_t wl = Gp.w1 - Gp.w0, o0 = (uint32_t)tid0 << 7, o1 = ((uint32_t)tid0 + NT) << 7;
+        if (o0 < wl) touch0 = *reinterpret_cast<const uint32_t*>(a.text + Gp.w0 + o0);
+        if (o1 < wl) touch1 = *reinterpret_cast<const uint32_t*>(a.text + Gp.w0 + o1);
+    };
 #if defined(MKT_XCD_MAP)
     // Workgroups go to the 8 XCDs round-robin (blockIdx & 7), each XCD has its own L2: give the workgroups of one XCD CONSECUTIVE
     // tiles, so that the halo a tile shares with its neighbour (6 of 54 KB) is fetched into that L2 once.
@@ -522,6 +533,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 }
             }
         }
+        if (MKT_TOUCH) asm volatile("" ::"v"(touch0), "v"(touch1));      // (keeps the two registers reserved until the loads have landed)
         __syncthreads();
         STAMP(1);
         STOP_AFTER(1)
@@ -607,6 +619,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         }
         __syncthreads();
         STOP_AFTER(9)
+        if (MKT_TOUCH == 1) touch_next(t + gridDim.x);
 
         // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
 #if defined(MKT_ROTATE)
@@ -640,6 +653,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         __syncthreads();
         STAMP(3);
         STOP_AFTER(3)
+        if (MKT_TOUCH == 2) touch_next(t + gridDim.x);
         const uint32_t NLe = fast_nle(st);
         const uint32_t first_idx = NL - st.c_t0 < NLe ? NL - st.c_t0 : NLe;
         const uint32_t end_idx = NL - st.c_t1 < NLe ? NL - st.c_t1 : NLe;
@@ -726,6 +740,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         __syncthreads();
         STAMP(7);
         STOP_AFTER(7)
+        if (MKT_TOUCH == 3) touch_next(t + gridDim.x);
 
         // ---- emit ----------------------------------------------------------------------------------
         const uint32_t total = st.sums.pair_bytes;
