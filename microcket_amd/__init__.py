@@ -23,9 +23,10 @@ from .capi import (  # noqa: F401
     load_library,
     rmdup,
     run_sam2pairs,
+    sam_to_bam,
 )
 
 __all__ = [
     "Context", "EXT_KEYS", "EXT_LANES", "MktError", "MODE_FLASH", "MODE_UNC", "PairsSorter", "TILES_AUTO", "TILES_FAST", "TILES_SMALL", "Stats",
-    "device_count", "exe_path", "lib_path", "load_library", "rmdup", "run_sam2pairs",
+    "device_count", "exe_path", "lib_path", "load_library", "rmdup", "run_sam2pairs", "sam_to_bam",
 ]

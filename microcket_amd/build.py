@@ -45,15 +45,36 @@ def hipcc():
 
 
 def _lib_sources():
-    return [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_sort.hip", "mkt_capi.cpp")]
+    return [os.path.join(CSRC, f) for f in ("mkt_kernels.hip", "mkt_sort.hip", "mkt_bam.hip", "mkt_capi.cpp")]
+
+
+OBJ = os.path.join(HERE, "_build", "obj")
+
+
+def _compile_objects(srcs, tag, flags):
+    """One object per source (rebuilt only when it or a header is newer): a change in one file does not recompile the kernels."""
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _headers()
+    objs, procs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, tag + os.path.basename(s) + ".o")
+        objs.append(o)
+        if _newer(o, [s] + hdrs):
+            cmd = [hipcc(), "-c", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", *flags, "-Wno-unused-function", "-I" + CSRC, s, "-o", o]
+            print("+", " ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    return objs
 
 
 def build_lib(force=False):
     srcs = _lib_sources()
     deps = srcs + _headers()
     if force or _newer(LIB, deps):
-        _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-Wall", "-Wno-unused-function",
-              "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", LIB])
+        objs = _compile_objects(srcs, "", ("-Wall",))
+        _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-Wl,-rpath,/opt/rocm/lib", *objs, "-o", LIB])
     return LIB
 
 
@@ -69,7 +90,7 @@ def build_stamps_lib(name="libmkt_hip_stamps.so", defines=("-DMKT_STAMPS",)):
 def build_variant(name, kernel_src=None, defines=()):
     """Experiment builds: another kernel source file and / or extra -D flags -> microcket_amd/<name> (select it with MKT_LIB)."""
     out = os.path.join(HERE, name)
-    srcs = [kernel_src or os.path.join(CSRC, "mkt_kernels.hip"), os.path.join(CSRC, "mkt_sort.hip"), os.path.join(CSRC, "mkt_capi.cpp")]
+    srcs = [kernel_src or os.path.join(CSRC, "mkt_kernels.hip")] + _lib_sources()[1:]
     _run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-O3", "-std=c++17", *defines, "-Wno-unused-function", "-I" + CSRC,
           "-Wl,-rpath,/opt/rocm/lib", *srcs, "-o", out])
     return out
@@ -114,6 +135,19 @@ def build_krmdup(force=False):
     return KRMDUP
 
 
+SAM2BAM = os.path.join(HERE, "bin", "sam2bam")
+
+
+def build_sam2bam(force=False):
+    """bin/sam2bam: the driver's `samtools view -b | samtools sort; samtools index` tail on the GPU."""
+    src = os.path.join(CSRC, "sam2bam_main.cpp")
+    if force or _newer(SAM2BAM, [src, LIB] + _headers()):
+        os.makedirs(os.path.dirname(SAM2BAM), exist_ok=True)
+        _run(["g++", "-O2", "-std=c++17", "-Wall", src, "-o", SAM2BAM, "-L" + HERE, "-lmkt_hip",
+              "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"])
+    return SAM2BAM
+
+
 MAKESTAT = os.path.join(HERE, "bin", "makestat")
 
 
@@ -151,6 +185,7 @@ def build_all(force=False, extras=True):
     build_exe(force)
     build_pairsort(force)
     build_krmdup(force)
+    build_sam2bam(force)
     build_makestat(force)
     if extras:
         build_oracle()

@@ -17,6 +17,7 @@ EXPORTS = [
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
     "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
     "mkt_rmdup_create", "mkt_rmdup_destroy", "mkt_rmdup_error", "mkt_rmdup_add", "mkt_rmdup_run", "mkt_rmdup_fetch",
+    "mkt_bam_create", "mkt_bam_destroy", "mkt_bam_error", "mkt_bam_add", "mkt_bam_add_device", "mkt_bam_run", "mkt_bam_fetch",
 ]
 
 
@@ -125,6 +126,15 @@ def load_library():
     L.mkt_rmdup_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.mkt_rmdup_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mkt_rmdup_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
+    L.mkt_bam_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.mkt_bam_destroy.argtypes = [C.c_void_p]
+    L.mkt_bam_destroy.restype = None
+    L.mkt_bam_error.argtypes = [C.c_void_p]
+    L.mkt_bam_error.restype = C.c_char_p
+    L.mkt_bam_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mkt_bam_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mkt_bam_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.mkt_bam_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -477,3 +487,32 @@ def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes"
     p = subprocess.run([exe, in_sam, mode, prefix, str(threads), str(ratio), str(mapq), sam], stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, env=e)
     return p.returncode, p.stdout, p.stderr
+
+
+def sam_to_bam(sam: bytes, sorted=True, level=1, device=0, piece=1 << 24):
+    """SAM text (header lines + alignment lines) -> (BAM bytes, BAI bytes or b"", records) on the GPU: mkt_bam_* in include/mkt.h."""
+    L = load_library()
+    h = C.c_void_p()
+    rc = L.mkt_bam_create(device, C.byref(h))
+    if rc != 0:
+        raise MktError(f"mkt_bam_create: {L.mkt_strerror(rc).decode()}")
+    try:
+        for k in range(0, len(sam), piece):
+            part = sam[k:k + piece]
+            rc = L.mkt_bam_add(h, part, len(part))
+            if rc != 0:
+                raise MktError(f"mkt_bam_add: {L.mkt_strerror(rc).decode()}: {L.mkt_bam_error(h).decode()}")
+        nrec, nbam, nbai = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc = L.mkt_bam_run(h, 1 if sorted else 0, level, C.byref(nrec), C.byref(nbam), C.byref(nbai))
+        if rc != 0:
+            raise MktError(f"mkt_bam_run: {L.mkt_strerror(rc).decode()}: {L.mkt_bam_error(h).decode()}")
+        outs = []
+        for which, n in ((0, nbam.value), (1, nbai.value)):
+            buf = C.create_string_buffer(max(n, 1))
+            rc = L.mkt_bam_fetch(h, which, 0, buf, n)
+            if rc != 0:
+                raise MktError(f"mkt_bam_fetch: {L.mkt_strerror(rc).decode()}: {L.mkt_bam_error(h).decode()}")
+            outs.append(buf.raw[:n])
+        return outs[0], outs[1], nrec.value
+    finally:
+        L.mkt_bam_destroy(h)

@@ -1,0 +1,1110 @@
+// mkt_bam.hip -- SURVEY.md 8(f) N3: the .sam -> BAM tail of the pipeline, on the GPU.
+//
+// The driver ends with (microcket:533-540)
+//     cat $samheader $sid.flash.sam $sid.unc.sam | samtools view -b | samtools sort -o $sid.valid.bam ;  samtools index $sid.valid.bam
+// i.e. the filtered alignments that sam2pairs wrote, as a coordinate-sorted, BGZF-compressed BAM with its .bai.  Here: newline
+// index, one key per line (reference id, position, strand), the stable LSD radix sort of mkt_sort.hip, an exclusive scan of the
+// record sizes, one pass that writes the binary records in sorted order, BGZF blocks (stored, or LZ77 + fixed-Huffman deflate,
+// CRC-32 per block) and the reductions the BAI needs (linear index, chunk starts, per-reference counts).  Byte / integer work
+// bound by HBM; no MFMA.
+//
+// Formats: SAM / BAM / BGZF / BAI as published in "Sequence Alignment/Map Format Specification" (samtools/hts-specs, SAMv1
+// sections 1.4, 4.1, 4.2, 5.2), RFC 1951 (deflate), RFC 1952 (gzip, CRC-32).  The reference ships samtools only as a prebuilt
+// third-party binary (bin/samtools), which is never run here: parity with it is UNPINNED.  What is checked instead
+// (tests/test_gpu_bam.py): every block inflates with Python's zlib (which verifies CRC-32 and ISIZE), an independent reader
+// written from the specification (tests/bamio.py) gets the input lines back in coordinate order, and every region query
+// through the .bai returns exactly the records a brute-force scan finds.  Conventions that the specification leaves open follow
+// htslib's documented behaviour: integer tags in the smallest type that holds them (unsigned types for values >= 0), `bin`
+// from [pos, end) with a length of 1 for unmapped reads or empty CIGARs, a mapped read without CIGAR marked unmapped, ties
+// of the sort key (reference, position, strand) in input order, @HD SO:coordinate set in the header of a sorted file.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mkt.h"
+#include "mkt_launch.h"
+#include "mkt_sortlib.h"
+
+using namespace mkt;
+
+namespace mkt {
+
+enum { BE_FIELDS = 1, BE_REF = 2, BE_NUM = 4, BE_CIGAR = 8, BE_TAG = 16, BE_SEQ = 32, BE_NAME = 64 };
+constexpr uint32_t BGZF_RAW = 0xff00;                 // uncompressed bytes per BGZF block (htslib's BGZF_BLOCK_SIZE)
+constexpr uint32_t BGZF_STRIDE = 0x10000;             // room for one compressed block in the work buffer (a block is <= 64 KiB)
+constexpr int BWG = 256;
+
+struct RefTab {                                       // reference names -> ids (built on the host from the @SQ lines)
+    const unsigned long long* hash;                   // FNV-1a of the name, 0 = empty
+    const int32_t* id;
+    const uint32_t* name_off;                         // per id: [off, off + len) in names
+    const uint8_t* names;
+    uint32_t mask, nref;
+};
+struct BamIdx { int32_t tid, beg, end; uint32_t bin; };     // per record, in file order: what the index needs (bin: low half; high half: FLAG)
+
+__device__ inline int32_t ref_lookup(const RefTab& rt, const uint8_t* t, uint64_t a, uint64_t b, uint32_t* err) {
+    unsigned long long h = 0xcbf29ce484222325ull;
+    for (uint64_t p = a; p < b; ++p) { h ^= t[p]; h *= 0x100000001b3ull; }
+    if (!h) h = 1;
+    uint32_t s = (uint32_t)(h >> 20) & rt.mask;
+    for (uint32_t probe = 0; probe <= rt.mask; ++probe) {
+        const unsigned long long cur = rt.hash[s];
+        if (cur == 0ull) break;
+        if (cur == h) {
+            const int32_t id = rt.id[s];
+            const uint32_t o = rt.name_off[id], l = rt.name_off[id + 1] - o;
+            bool same = l == (uint32_t)(b - a);
+            for (uint32_t i = 0; same && i < l; ++i) same = rt.names[o + i] == t[a + i];
+            if (same) return id;
+        }
+        s = (s + 1u) & rt.mask;
+    }
+    atomicOr(err, (uint32_t)BE_REF);
+    return -1;
+}
+__device__ inline uint32_t reg2bin(int64_t beg, int64_t end) {        // SAMv1 5.3
+    --end;
+    if (beg >> 14 == end >> 14) return (uint32_t)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (uint32_t)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (uint32_t)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (uint32_t)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (uint32_t)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+__device__ inline void put8(uint8_t*& o, uint32_t v) { *o++ = (uint8_t)v; }
+__device__ inline void put16(uint8_t*& o, uint32_t v) { o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o += 2; }
+__device__ inline void put32(uint8_t*& o, uint32_t v) { o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); o[3] = (uint8_t)(v >> 24); o += 4; }
+
+// unsigned decimal in [a, b); *ok cleared when it is not one
+__device__ inline uint64_t dec_u(const uint8_t* t, uint64_t a, uint64_t b, bool* ok) {
+    if (a >= b || b - a > 19) { *ok = false; return 0; }
+    uint64_t v = 0;
+    for (uint64_t p = a; p < b; ++p) { const uint32_t d = (uint32_t)t[p] - 48u; if (d > 9u) { *ok = false; return 0; } v = v * 10 + d; }
+    return v;
+}
+__device__ inline int64_t dec_s(const uint8_t* t, uint64_t a, uint64_t b, bool* ok) {
+    bool neg = false;
+    if (a < b && (t[a] == '-' || t[a] == '+')) { neg = t[a] == '-'; ++a; }
+    const uint64_t v = dec_u(t, a, b, ok);
+    if (v > (1ull << 62)) { *ok = false; return 0; }
+    return neg ? -(int64_t)v : (int64_t)v;
+}
+// decimal floating point text -> float (tags of type f and B:f).  Mantissa of up to 19 digits, power of ten applied in double:
+// exact for every value samtools itself prints with %g (<= 9 significant digits, |exponent| <= 22); beyond that the result can
+// differ from strtof in the last bit.
+__device__ inline float dec_f(const uint8_t* t, uint64_t a, uint64_t b, bool* ok) {
+    bool neg = false;
+    if (a < b && (t[a] == '-' || t[a] == '+')) { neg = t[a] == '-'; ++a; }
+    uint64_t m = 0;
+    int nd = 0, e10 = 0;
+    bool any = false, dot = false;
+    uint64_t p = a;
+    for (; p < b; ++p) {
+        const uint8_t c = t[p];
+        if (c == '.' && !dot) { dot = true; continue; }
+        const uint32_t d = (uint32_t)c - 48u;
+        if (d > 9u) break;
+        any = true;
+        if (nd < 19) { m = m * 10 + d; if (m) ++nd; if (dot) --e10; }
+        else if (!dot) ++e10;
+    }
+    if (!any) { *ok = false; return 0.f; }
+    if (p < b) {
+        if (t[p] != 'e' && t[p] != 'E') { *ok = false; return 0.f; }
+        bool eok = true;
+        const int64_t ee = dec_s(t, p + 1, b, &eok);
+        if (!eok || ee > 400 || ee < -400) { *ok = false; return 0.f; }
+        e10 += (int)ee;
+    }
+    double d = (double)m;
+    const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    int e = e10;
+    while (e > 22) { d *= 1e22; e -= 22; }
+    while (e < -22) { d /= 1e22; e += 22; }
+    d = e >= 0 ? d * p10[e] : d / p10[-e];
+    const float f = (float)d;
+    return neg ? -f : f;
+}
+
+__device__ inline uint32_t seq_code(uint8_t c) {      // SAMv1 4.2: "=ACMGRSVTWYHKDBN", anything else (and lower case alike) -> N
+    switch (c & 0xDF) {                                // upper case
+        case 'A': return 1; case 'C': return 2; case 'M': return 3; case 'G': return 4; case 'R': return 5; case 'S': return 6;
+        case 'V': return 7; case 'T': return 8; case 'W': return 9; case 'Y': return 10; case 'H': return 11; case 'K': return 12;
+        case 'D': return 13; case 'B': return 14; default: break;
+    }
+    return c == '=' ? 0u : 15u;
+}
+__device__ inline int cigar_op(uint8_t c) {
+    switch (c) { case 'M': return 0; case 'I': return 1; case 'D': return 2; case 'N': return 3; case 'S': return 4; case 'H': return 5;
+                 case 'P': return 6; case '=': return 7; case 'X': return 8; default: return -1; }
+}
+
+// One alignment line -> its BAM record.  WRITE = false: sizes and keys only.  Returns the record's bytes (block_size + 4), 0 on error.
+template <bool WRITE>
+__device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const RefTab& rt, uint8_t* out, BamIdx* ix, uint32_t* err) {
+    uint64_t tab[11];
+    int nt = 0;
+    for (uint64_t p = ls; p < le && nt < 11; ++p) if (t[p] == '\t') tab[nt++] = p;
+    if (nt < 10) { atomicOr(err, (uint32_t)BE_FIELDS); return 0; }
+    const uint64_t qual_end = nt == 11 ? tab[10] : le;
+    bool ok = true;
+    const uint64_t l_qname = tab[0] - ls;
+    if (l_qname == 0 || l_qname > 254) { atomicOr(err, (uint32_t)BE_NAME); return 0; }
+    uint64_t flag = dec_u(t, tab[0] + 1, tab[1], &ok);
+    const int64_t pos1 = dec_s(t, tab[2] + 1, tab[3], &ok);
+    const uint64_t mapq = dec_u(t, tab[3] + 1, tab[4], &ok);
+    const int64_t pnext1 = dec_s(t, tab[6] + 1, tab[7], &ok);
+    const int64_t tlen = dec_s(t, tab[7] + 1, tab[8], &ok);
+    if (!ok || flag > 65535 || mapq > 255 || pos1 < 0 || pos1 > 0x7fffffffll || pnext1 < 0 || pnext1 > 0x7fffffffll || tlen > 0x7fffffffll || tlen < -0x80000000ll) {
+        atomicOr(err, (uint32_t)BE_NUM);
+        return 0;
+    }
+    int32_t tid = -1, mtid = -1;
+    {
+        const uint64_t a = tab[1] + 1, b = tab[2];
+        if (!(b - a == 1 && t[a] == '*')) tid = ref_lookup(rt, t, a, b, err);
+        const uint64_t c = tab[5] + 1, d = tab[6];
+        if (d - c == 1 && t[c] == '=') mtid = tid;
+        else if (!(d - c == 1 && t[c] == '*')) mtid = ref_lookup(rt, t, c, d, err);
+    }
+    // CIGAR
+    const uint64_t ca = tab[4] + 1, cb = tab[5];
+    uint32_t n_cigar = 0;
+    int64_t rlen = 0;
+    const bool no_cigar = cb - ca == 1 && t[ca] == '*';
+    if (no_cigar) { if (!(flag & 4u)) flag |= 4u; }          // "mapped query must have a CIGAR; treated as unmapped"
+    else {
+        uint64_t v = 0;
+        bool digits = false;
+        for (uint64_t p = ca; p < cb; ++p) {
+            const uint32_t d = (uint32_t)t[p] - 48u;
+            if (d <= 9u) { v = v * 10 + d; digits = true; if (v >= (1ull << 28)) { atomicOr(err, (uint32_t)BE_CIGAR); return 0; } continue; }
+            const int op = cigar_op(t[p]);
+            if (op < 0 || !digits) { atomicOr(err, (uint32_t)BE_CIGAR); return 0; }
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += (int64_t)v;
+            ++n_cigar; v = 0; digits = false;
+        }
+        if (digits || n_cigar == 0 || n_cigar > 65535) { atomicOr(err, (uint32_t)BE_CIGAR); return 0; }
+    }
+    // SEQ / QUAL
+    const uint64_t sa = tab[8] + 1, sb = tab[9], qa = tab[9] + 1, qb = qual_end;
+    const uint32_t l_seq = (sb - sa == 1 && t[sa] == '*') ? 0u : (uint32_t)(sb - sa);
+    const bool no_qual = qb - qa == 1 && t[qa] == '*';                     // (also for a 1-base read, as in htslib)
+    if (!no_qual && (qb - qa) != l_seq) { atomicOr(err, (uint32_t)BE_SEQ); return 0; }
+    const int32_t pos = (int32_t)pos1 - 1;
+    int64_t span = ((flag & 4u) || rlen == 0) ? 1 : rlen;
+    const int64_t end = (int64_t)pos + span;
+    const uint32_t bin = reg2bin(pos, end);
+    uint8_t* o = out;
+    if (WRITE) {
+        o += 4;                                                // block_size: at the end
+        put32(o, (uint32_t)tid);
+        put32(o, (uint32_t)pos);
+        put8(o, (uint32_t)l_qname + 1u);
+        put8(o, (uint32_t)mapq);
+        put16(o, bin);
+        put16(o, n_cigar);
+        put16(o, (uint32_t)flag);
+        put32(o, l_seq);
+        put32(o, (uint32_t)mtid);
+        put32(o, (uint32_t)((int32_t)pnext1 - 1));
+        put32(o, (uint32_t)(int32_t)tlen);
+        for (uint64_t p = ls; p < tab[0]; ++p) *o++ = t[p];
+        *o++ = 0;
+        if (!no_cigar) {
+            uint32_t v = 0;
+            for (uint64_t p = ca; p < cb; ++p) {
+                const uint32_t d = (uint32_t)t[p] - 48u;
+                if (d <= 9u) { v = v * 10 + d; continue; }
+                put32(o, (v << 4) | (uint32_t)cigar_op(t[p]));
+                v = 0;
+            }
+        }
+        for (uint32_t k = 0; k + 1 < l_seq; k += 2) *o++ = (uint8_t)((seq_code(t[sa + k]) << 4) | seq_code(t[sa + k + 1]));
+        if (l_seq & 1u) *o++ = (uint8_t)(seq_code(t[sa + l_seq - 1]) << 4);
+        if (no_qual) for (uint32_t k = 0; k < l_seq; ++k) *o++ = 0xFF;
+        else for (uint32_t k = 0; k < l_seq; ++k) *o++ = (uint8_t)(t[qa + k] - 33u);
+    }
+    uint32_t size = 4 + 32 + (uint32_t)l_qname + 1 + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
+    // optional fields  TG:T:value
+    uint64_t p = nt == 11 ? tab[10] + 1 : le;
+    while (p < le) {
+        uint64_t q = p;
+        while (q < le && t[q] != '\t') ++q;
+        if (q - p < 5 || t[p + 2] != ':' || t[p + 4] != ':') { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+        const uint8_t ty = t[p + 3];
+        const uint64_t va = p + 5, vb = q;
+        if (WRITE) { *o++ = t[p]; *o++ = t[p + 1]; }
+        size += 2;
+        bool tok = true;
+        if (ty == 'A' || ty == 'a' || ty == 'c' || ty == 'C') {      // (htslib reads the lower-case forms of the BAM types as A)
+            if (vb - va != 1) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            if (WRITE) { *o++ = 'A'; *o++ = t[va]; }
+            size += 2;
+        } else if (ty == 'i' || ty == 'I') {
+            const bool neg = va < vb && t[va] == '-';
+            const int64_t x = dec_s(t, va, vb, &tok);
+            if (!tok || x < -0x80000000ll || x > 0xffffffffll) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            char c; uint32_t w;
+            if (neg) { if (x >= -128) { c = 'c'; w = 1; } else if (x >= -32768) { c = 's'; w = 2; } else { c = 'i'; w = 4; } }
+            else { if (x <= 255) { c = 'C'; w = 1; } else if (x <= 65535) { c = 'S'; w = 2; } else { c = 'I'; w = 4; } }
+            if (WRITE) { *o++ = (uint8_t)c; if (w == 1) put8(o, (uint32_t)x); else if (w == 2) put16(o, (uint32_t)x); else put32(o, (uint32_t)x); }
+            size += 1 + w;
+        } else if (ty == 'f') {
+            const float f = dec_f(t, va, vb, &tok);
+            if (!tok) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            if (WRITE) { *o++ = 'f'; put32(o, __float_as_uint(f)); }
+            size += 5;
+        } else if (ty == 'Z' || ty == 'H') {
+            if (WRITE) { *o++ = ty; for (uint64_t k = va; k < vb; ++k) *o++ = t[k]; *o++ = 0; }
+            size += 2 + (uint32_t)(vb - va);
+        } else if (ty == 'B') {
+            if (va >= vb) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            const uint8_t sub = t[va];
+            uint32_t w = 0;
+            switch (sub) { case 'c': case 'C': w = 1; break; case 's': case 'S': w = 2; break; case 'i': case 'I': case 'f': w = 4; break; default: break; }
+            if (!w) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            uint32_t cnt = 0;
+            for (uint64_t k = va + 1; k < vb; ++k) if (t[k] == ',') ++cnt;
+            if (va + 1 < vb && t[va + 1] != ',') { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            if (WRITE) {
+                *o++ = 'B'; *o++ = sub; put32(o, cnt);
+                uint64_t k = va + 2;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    uint64_t e = k;
+                    while (e < vb && t[e] != ',') ++e;
+                    if (sub == 'f') put32(o, __float_as_uint(dec_f(t, k, e, &tok)));
+                    else { const int64_t x = dec_s(t, k, e, &tok); if (w == 1) put8(o, (uint32_t)x); else if (w == 2) put16(o, (uint32_t)x); else put32(o, (uint32_t)x); }
+                    k = e + 1;
+                }
+            } else {
+                uint64_t k = va + 2;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    uint64_t e = k;
+                    while (e < vb && t[e] != ',') ++e;
+                    if (sub == 'f') (void)dec_f(t, k, e, &tok); else (void)dec_s(t, k, e, &tok);
+                    k = e + 1;
+                }
+            }
+            if (!tok) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+            size += 2 + 4 + cnt * w;
+        } else { atomicOr(err, (uint32_t)BE_TAG); return 0; }
+        p = q + 1;
+    }
+    if (WRITE) { uint8_t* h = out; put32(h, size - 4); }
+    if (ix) { ix->tid = tid; ix->beg = pos; ix->end = (int32_t)(end > 0x7fffffffll ? 0x7fffffffll : end); ix->bin = bin | ((uint32_t)flag << 16); }
+    return size;
+}
+
+// pass 1: size of every line's record + its sort key ((tid, -1 last) | pos + 1 | reverse strand), idx = line
+__global__ void k_bam_keys(const uint8_t* text, const uint64_t* starts, uint64_t nlines, RefTab rt, SortRec* rec, uint32_t* size, uint32_t* err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nlines) return;
+    BamIdx ix;
+    ix.tid = -1; ix.beg = -1; ix.end = 0; ix.bin = 0;
+    uint64_t le = starts[j + 1] - 1;
+    const uint64_t ls = starts[j];
+    if (le > ls && text[le - 1] == '\r') --le;
+    const uint32_t sz = bam_record<false>(text, ls, le, rt, nullptr, &ix, err);
+    size[j] = sz;
+    SortRec r;
+    const uint64_t tkey = ix.tid < 0 ? (uint64_t)rt.nref : (uint64_t)ix.tid;
+    r.hi = (tkey << 33) | ((uint64_t)(uint32_t)(ix.beg + 1) << 1) | ((ix.bin >> 20) & 1u);       // FLAG 0x10: reverse strand
+    r.lo = 0; r.idx = (uint32_t)j;
+    rec[j] = r;
+}
+__global__ void k_bam_sizes(const SortRec* rec, const uint32_t* size, uint64_t n, uint64_t* off) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) off[r] = size[rec[r].idx];
+}
+// pass 2: the records, in file order
+__global__ void k_bam_write(const uint8_t* text, const uint64_t* starts, uint64_t n, RefTab rt, const SortRec* rec, const uint64_t* off, uint8_t* raw, BamIdx* idx, uint32_t* err) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t j = rec[r].idx;
+    uint64_t le = starts[j + 1] - 1;
+    const uint64_t ls = starts[j];
+    if (le > ls && text[le - 1] == '\r') --le;
+    BamIdx ix;
+    (void)bam_record<true>(text, ls, le, rt, raw + off[r], &ix, err);
+    idx[r] = ix;
+}
+
+// ---- CRC-32 (RFC 1952) of a block: every thread takes a slice, the slices are combined as polynomials ------------------------
+__device__ inline uint32_t crc_mulmod(uint32_t a, uint32_t b) {       // a(x) * b(x) mod P(x), reflected representation (zlib's multmodp)
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1u)) == 0u) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+__device__ inline uint32_t crc_x8n(uint32_t nbytes, const uint32_t* x2n /* x^(2^k) mod P, k = 0..31 */) {        // x^(8 * nbytes) mod P
+    uint32_t p = 1u << 31;                                            // the polynomial 1
+    uint32_t n = nbytes;
+    int k = 3;                                                        // bits -> bytes
+    while (n) { if (n & 1u) p = crc_mulmod(x2n[k & 31], p); n >>= 1; ++k; }
+    return p;
+}
+__device__ inline uint32_t crc_bytes(const uint8_t* d, uint32_t n, const uint32_t* tabl) {
+    uint32_t c = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n; ++i) c = tabl[(c ^ d[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+struct CrcTabs { uint32_t t[256]; uint32_t x2n[32]; };
+
+// block-wide CRC of n bytes at src (global or LDS): slices of ceil(n / BWG) bytes
+__device__ inline uint32_t block_crc(const uint8_t* src, uint32_t n, const uint32_t* tabl, const uint32_t* x2n, uint32_t* sh /* [BWG / 64] */) {
+    const uint32_t per = (n + BWG - 1) / BWG;
+    const uint32_t a = threadIdx.x * per < n ? threadIdx.x * per : n, b = a + per < n ? a + per : n;
+    uint32_t c = 0;
+    if (b > a) { c = crc_bytes(src + a, b - a, tabl); if (n - b) c = crc_mulmod(crc_x8n(n - b, x2n), c); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c ^= (uint32_t)__shfl_xor((int)c, d, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    uint32_t r = 0;
+#pragma unroll
+    for (int w = 0; w < BWG / 64; ++w) r ^= sh[w];
+    __syncthreads();
+    return r;
+}
+__device__ inline void bgzf_header(uint8_t* o, uint32_t bsize_minus1) {     // SAMv1 4.1
+    const uint8_t h[16] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0};
+    for (int i = 0; i < 16; ++i) o[i] = h[i];
+    o[16] = (uint8_t)bsize_minus1; o[17] = (uint8_t)(bsize_minus1 >> 8);
+}
+
+// level 0: one stored deflate block per BGZF block
+__global__ __launch_bounds__(BWG) void k_bgzf_stored(const uint8_t* raw, uint64_t nraw, const CrcTabs* ct, uint8_t* comp, uint64_t* csize) {
+    __shared__ uint32_t tabl[256], x2n[32], sh[BWG / 64];
+    tabl[threadIdx.x] = ct->t[threadIdx.x];
+    if (threadIdx.x < 32) x2n[threadIdx.x] = ct->x2n[threadIdx.x];
+    __syncthreads();
+    const uint64_t b0 = (uint64_t)blockIdx.x * BGZF_RAW;
+    const uint32_t n = (uint32_t)(nraw - b0 < BGZF_RAW ? nraw - b0 : BGZF_RAW);
+    const uint8_t* src = raw + b0;
+    uint8_t* o = comp + (uint64_t)blockIdx.x * BGZF_STRIDE;
+    const uint32_t crc = block_crc(src, n, tabl, x2n, sh);
+    const uint32_t total = 18 + 5 + n + 8;
+    if (threadIdx.x == 0) {
+        bgzf_header(o, total - 1);
+        o[18] = 1;                                         // BFINAL = 1, BTYPE = 00
+        o[19] = (uint8_t)n; o[20] = (uint8_t)(n >> 8); o[21] = (uint8_t)~n; o[22] = (uint8_t)(~n >> 8);
+        uint8_t* e = o + 23 + n;
+        put32(e, crc); put32(e, n);
+        csize[blockIdx.x] = total;
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += BWG) o[23 + i] = src[i];
+}
+// the compressed blocks, packed
+__global__ __launch_bounds__(BWG) void k_bgzf_pack(const uint8_t* comp, const uint64_t* coff, uint64_t nblocks, uint8_t* out) {
+    const uint64_t b = blockIdx.x;
+    const uint64_t o = coff[b], n = coff[b + 1] - o;
+    const uint8_t* s = comp + b * BGZF_STRIDE;
+    for (uint32_t i = threadIdx.x; i < n; i += BWG) out[o + i] = s[i];
+}
+
+// ---- level 1: LZ77 + fixed Huffman codes (RFC 1951 3.2.6), one workgroup per BGZF block --------------------------------------
+// Every wave compresses a quarter of the block with its own hash table (matches stay inside the quarter, <= 16 KiB back), 64
+// positions per step: a hash of four bytes names a candidate from earlier steps (plus distance 1 for runs), lengths are
+// compared, the greedy parse of the step (which positions start a token) comes from pointer doubling over the wave, the bit
+// lengths are scanned and the codes ORed into the wave's stream.  The four streams are then joined bit-exactly.
+constexpr uint32_t DZ_Q = BGZF_RAW / 4;                  // 16320 bytes per wave
+constexpr uint32_t DZ_HBITS = 12;
+constexpr uint32_t DZ_MAXLEN = 258, DZ_MINLEN = 4;
+constexpr uint32_t DZ_QWORDS = (DZ_Q * 9 / 8 + 64) / 4 + 2;       // worst case 9 bits per literal
+
+__device__ inline uint32_t bitrev(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+// fixed Huffman code of a literal / length symbol, already reversed for LSB-first packing
+__device__ inline void fix_litlen(uint32_t sym, uint32_t& code, uint32_t& nb) {
+    if (sym < 144) { code = bitrev(0x30 + sym, 8); nb = 8; }
+    else if (sym < 256) { code = bitrev(0x190 + (sym - 144), 9); nb = 9; }
+    else if (sym < 280) { code = bitrev(sym - 256, 7); nb = 7; }
+    else { code = bitrev(0xC0 + (sym - 280), 8); nb = 8; }
+}
+__device__ inline void len_code(uint32_t len, uint32_t& sym, uint32_t& eb, uint32_t& ev) {       // 3..258
+    if (len == 258) { sym = 285; eb = 0; ev = 0; return; }
+    const uint32_t l = len - 3;
+    if (l < 8) { sym = 257 + l; eb = 0; ev = 0; return; }
+    const uint32_t k = 31u - (uint32_t)__clz((int)l);          // 3..7
+    eb = k - 2;
+    sym = 257 + 4 * eb + 4 + ((l >> eb) & 3u);
+    ev = l & ((1u << eb) - 1u);
+}
+__device__ inline void dist_code(uint32_t dist, uint32_t& sym, uint32_t& eb, uint32_t& ev) {     // 1..32768
+    const uint32_t d = dist - 1;
+    if (d < 4) { sym = d; eb = 0; ev = 0; return; }
+    const uint32_t k = 31u - (uint32_t)__clz((int)d);
+    eb = k - 1;
+    sym = 2 * k + ((d >> eb) & 1u);
+    ev = d & ((1u << eb) - 1u);
+}
+
+__global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64_t nraw, const CrcTabs* ct, uint8_t* comp, uint64_t* csize, uint32_t* scratch /* per block 4 * DZ_QWORDS */) {
+    __shared__ uint8_t in[BGZF_RAW + 16];
+    __shared__ uint32_t htab[4][1u << DZ_HBITS];
+    __shared__ uint32_t stage_[4][80];                    // one step's bits of a wave: 64 tokens of <= 31 bits + the carry
+    __shared__ uint32_t tabl[256], x2n[32], sh[BWG / 64];
+    __shared__ uint32_t wbits[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    volatile uint32_t (*stage)[80] = stage_;             // lanes of a wave hand bits to each other through it
+    tabl[tid] = ct->t[tid];
+    if (tid < 32) x2n[tid] = ct->x2n[tid];
+    const uint64_t b0 = (uint64_t)blockIdx.x * BGZF_RAW;
+    const uint32_t n = (uint32_t)(nraw - b0 < BGZF_RAW ? nraw - b0 : BGZF_RAW);
+    for (uint32_t i = tid; i < BGZF_RAW + 16; i += BWG) in[i] = i < n ? raw[b0 + i] : 0;
+    for (uint32_t i = lane; i < (1u << DZ_HBITS); i += 64) htab[wv][i] = 0;          // 0 = empty (positions are stored + 1)
+    __syncthreads();
+    const uint32_t crc = block_crc(in, n, tabl, x2n, sh);
+    // ---- this wave's quarter
+    const uint32_t q0 = wv * DZ_Q < n ? wv * DZ_Q : n, q1 = q0 + DZ_Q < n ? q0 + DZ_Q : n;
+    uint32_t* ws = scratch + ((uint64_t)blockIdx.x * 4 + wv) * DZ_QWORDS;
+    uint32_t wpos = 0;                                   // whole words already flushed to ws
+    uint32_t carry_bits = 0;                             // bits waiting in stage[wv][0]
+    if (wv == 0) { if (lane == 0) stage[0][0] = 3u; carry_bits = 3; }        // BFINAL = 1, BTYPE = 01 (bits: 1, then 01 LSB first = 1 | 1 << 1)
+    else if (lane == 0) stage[wv][0] = 0;
+    uint32_t cur = q0;                                   // first position not yet covered by a token
+    for (uint32_t base = q0; base < q1; base += 64) {
+        const uint32_t p = base + lane;
+        const bool live = p < q1;
+        uint32_t mlen = 0, mdist = 0;
+        uint32_t h = 0;
+        const bool hashable = live && p + DZ_MINLEN <= q1;
+        if (hashable) {
+            const uint32_t v = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+            h = (v * 2654435761u) >> (32 - DZ_HBITS);
+            const uint32_t c1 = htab[wv][h];
+            const uint32_t lim = q1 - p < DZ_MAXLEN ? q1 - p : DZ_MAXLEN;
+            if (c1) {
+                const uint32_t c = c1 - 1;               // < base: only earlier steps have written
+                uint32_t l = 0;
+                while (l < lim && in[c + l] == in[p + l]) ++l;
+                if (l >= DZ_MINLEN) { mlen = l; mdist = p - c; }
+            }
+            if (p > q0 && mlen < lim) {                  // runs: distance 1
+                uint32_t l = 0;
+                while (l < lim && in[p - 1 + l] == in[p + l]) ++l;
+                if (l >= DZ_MINLEN && l > mlen) { mlen = l; mdist = 1; }
+            }
+        }
+        // (all lanes have read the table before any lane of this wave writes: one wave, program order)
+        if (hashable) atomicMax(&htab[wv][h], p + 1);
+        // greedy parse of the step by pointer doubling: nxt = first position after this position's token
+        uint32_t nxt = live ? lane + (mlen ? mlen : 1u) : 64u;           // relative to base; >= 64: leaves the step
+        if (nxt < 64u && base + nxt >= q1) nxt = 64u;     // the quarter ends inside this step: the lanes behind it are not positions
+        uint64_t vis = 1ull << lane;                      // positions visited from here (inside the step)
+        uint32_t f = nxt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t src = f < 64u ? f : (uint32_t)lane;
+            const uint64_t v2 = (uint64_t)__shfl((long long)vis, (int)src, 64);
+            const uint32_t f2 = (uint32_t)__shfl((int)f, (int)src, 64);
+            if (f < 64u) { vis |= v2; f = f2; }
+        }
+        const uint32_t start = cur - base;                // < 64 or the whole step is covered
+        uint64_t sel = 0;
+        uint32_t fend = start;
+        if (start < 64u && cur < q1) {                   // (cur == q1: the last token ended with the quarter)
+            sel = (uint64_t)__shfl((long long)vis, (int)start, 64);
+            fend = (uint32_t)__shfl((int)f, (int)start, 64);
+        }
+        cur = base + fend;                                // (uniform)
+        const bool mine = (sel >> lane) & 1ull;
+        // token bits
+        uint64_t bits = 0;
+        uint32_t nb = 0;
+        if (mine) {
+            if (mlen) {
+                uint32_t sym, eb, ev, code, cb;
+                len_code(mlen, sym, eb, ev);
+                fix_litlen(sym, code, cb);
+                bits = code; nb = cb;
+                bits |= (uint64_t)ev << nb; nb += eb;
+                uint32_t ds, deb, dev;
+                dist_code(mdist, ds, deb, dev);
+                bits |= (uint64_t)bitrev(ds, 5) << nb; nb += 5;
+                bits |= (uint64_t)dev << nb; nb += deb;
+            } else {
+                uint32_t code, cb;
+                fix_litlen(in[p], code, cb);
+                bits = code; nb = cb;
+            }
+        }
+        // bit offsets inside the step
+        uint32_t inc = nb;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += y; }
+        const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
+        const uint32_t bo = carry_bits + inc - nb;
+        // stage[1..] cleared for this step (word 0 holds the carry)
+        for (uint32_t i = 1 + lane; i < 80; i += 64) stage[wv][i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (nb) {
+            const uint32_t w = bo >> 5, s = bo & 31u;
+            const uint64_t lo = bits << s;
+            atomicOr(&stage_[wv][w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(&stage_[wv][w + 1], (uint32_t)(lo >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t endb = carry_bits + tot, full = endb >> 5;
+        for (uint32_t i = lane; i < full; i += 64) ws[wpos + i] = stage[wv][i];
+        const uint32_t rest = stage[wv][full];
+        __builtin_amdgcn_wave_barrier();
+        wpos += full;
+        carry_bits = endb & 31u;
+        if (lane == 0) stage[wv][0] = carry_bits ? rest : 0u;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { ws[wpos] = stage[wv][0]; wbits[wv] = wpos * 32u + carry_bits; }
+    __threadfence_block();
+    __syncthreads();
+    // ---- join: stream 0 .. 3, then the end-of-block code (7 zero bits)
+    const uint32_t nb0 = wbits[0], nb1 = wbits[1], nb2 = wbits[2], nb3 = wbits[3];
+    const uint32_t o1 = nb0, o2 = o1 + nb1, o3 = o2 + nb2, oe = o3 + nb3, total_bits = oe + 7u;
+    const uint32_t cbytes = (total_bits + 7u) >> 3;
+    uint8_t* o = comp + (uint64_t)blockIdx.x * BGZF_STRIDE;
+    if (cbytes >= n + 5u) {                               // did not shrink: stored
+        const uint32_t total = 18 + 5 + n + 8;
+        if (tid == 0) {
+            bgzf_header(o, total - 1);
+            o[18] = 1; o[19] = (uint8_t)n; o[20] = (uint8_t)(n >> 8); o[21] = (uint8_t)~n; o[22] = (uint8_t)(~n >> 8);
+            uint8_t* e = o + 23 + n;
+            put32(e, crc); put32(e, n);
+            csize[blockIdx.x] = total;
+        }
+        for (uint32_t i = tid; i < n; i += BWG) o[23 + i] = in[i];
+        return;
+    }
+    const uint32_t* s0 = scratch + ((uint64_t)blockIdx.x * 4) * DZ_QWORDS;
+    // output word k holds bits [32 k, 32 k + 32) of the joined stream: each comes from one or two streams
+    const uint32_t nwords = (total_bits + 31u) >> 5;
+    for (uint32_t k = tid; k < nwords; k += BWG) {
+        uint32_t word = 0;
+        const uint32_t lo = k << 5, hi = lo + 32u;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t so = s == 0 ? 0u : (s == 1 ? o1 : (s == 2 ? o2 : o3)), sn = s == 0 ? nb0 : (s == 1 ? nb1 : (s == 2 ? nb2 : nb3));
+            if (sn == 0u || so >= hi || so + sn <= lo) continue;
+            const uint32_t* sw = s0 + (uint64_t)s * DZ_QWORDS;
+            // bits of stream s that land in this word: stream bit j -> joined bit so + j
+            const int64_t j0 = (int64_t)lo - (int64_t)so;            // stream bit at the word's bit 0 (may be negative)
+            uint32_t v;
+            if (j0 >= 0) {
+                const uint32_t w = (uint32_t)j0 >> 5, sft = (uint32_t)j0 & 31u;
+                const uint64_t two = (uint64_t)sw[w] | ((uint64_t)(((w + 1u) << 5) < sn ? sw[w + 1] : 0u) << 32);
+                v = (uint32_t)(two >> sft);
+                const uint32_t avail = sn - (uint32_t)j0;             // stream bits from j0 on
+                if (avail < 32u) v &= (1u << avail) - 1u;
+            } else {
+                const uint32_t sft = (uint32_t)(-j0);                 // 1..31
+                v = sw[0] << sft;
+                const uint32_t avail = sn;                            // lands at [sft, sft + sn)
+                if (avail + sft < 32u) v &= (1u << (avail + sft)) - 1u;
+            }
+            word |= v;
+        }
+        uint8_t* d = o + 18 + 4u * k;
+        const uint32_t left = cbytes - 4u * k;
+        d[0] = (uint8_t)word;
+        if (left > 1) d[1] = (uint8_t)(word >> 8);
+        if (left > 2) d[2] = (uint8_t)(word >> 16);
+        if (left > 3) d[3] = (uint8_t)(word >> 24);
+    }
+    if (tid == 0) {
+        const uint32_t total = 18 + cbytes + 8;
+        bgzf_header(o, total - 1);
+        uint8_t* e = o + 18 + cbytes;
+        put32(e, crc); put32(e, n);
+        csize[blockIdx.x] = total;
+    }
+}
+
+// ---- BAI reductions -------------------------------------------------------------------------------------------------------
+struct BaiHead { uint32_t r; int32_t tid; uint32_t bin; uint32_t pad; uint64_t voff; };
+struct BaiRef { unsigned long long n_mapped, n_unmapped, beg, end; };          // beg: min start voffset, end: max end voffset
+__device__ inline uint64_t voffset(uint64_t uoff, const uint64_t* coff) {
+    const uint64_t b = uoff / BGZF_RAW;
+    return (coff[b] << 16) | (uoff - b * BGZF_RAW);
+}
+__global__ void k_bai(const BamIdx* idx, const uint64_t* off /* [n + 1] */, uint64_t n, uint64_t hdr_len, const uint64_t* coff, const uint64_t* lin_off, uint32_t nref,
+                      unsigned long long* lin, BaiRef* refs, BaiHead* heads, uint32_t* nheads, uint32_t heads_cap, unsigned long long* no_coor) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const BamIdx x = idx[r];
+    if (x.tid < 0) { atomicAdd(no_coor, 1ull); return; }
+    const uint64_t v0 = voffset(hdr_len + off[r], coff), v1 = voffset(hdr_len + off[r + 1], coff);
+    const uint32_t bin = x.bin & 0xFFFFu;
+    BaiRef* R = &refs[x.tid];
+    if ((x.bin >> 18) & 1u) atomicAdd(&R->n_unmapped, 1ull); else atomicAdd(&R->n_mapped, 1ull);       // FLAG 0x4
+    atomicMin(&R->beg, (unsigned long long)v0);
+    atomicMax(&R->end, (unsigned long long)v1);
+    const uint64_t nwin = lin_off[x.tid + 1] - lin_off[x.tid];
+    int64_t w0 = x.beg < 0 ? 0 : (x.beg >> 14), w1 = (x.end > 0 ? x.end - 1 : 0) >> 14;
+    if (w1 < w0) w1 = w0;
+    for (int64_t w = w0; w <= w1 && (uint64_t)w < nwin; ++w) atomicMin(&lin[lin_off[x.tid] + (uint64_t)w], (unsigned long long)v0);
+    bool head = r == 0;
+    if (!head) { const BamIdx y = idx[r - 1]; head = y.tid != x.tid || (y.bin & 0xFFFFu) != bin; }
+    if (head) {
+        const uint32_t k = atomicAdd(nheads, 1u);
+        if (k < heads_cap) { BaiHead h; h.r = (uint32_t)r; h.tid = x.tid; h.bin = bin; h.pad = 0; h.voff = v0; heads[k] = h; }
+    }
+}
+
+}  // namespace mkt
+
+// ---------------------------------------------------------------------------------------------------------------------------
+struct mkt_bam {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* d_text = nullptr; size_t cap = 0, len = 0;
+    bool header_done = false, ran = false;
+    std::string header, pending;
+    uint8_t* d_bam = nullptr; uint64_t bam_len = 0;
+    std::string bai;
+    uint64_t records = 0;
+    std::string err;
+};
+static int bfail(mkt_bam* s, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (s) s->err = buf;
+    return code;
+}
+#define BCHK(s, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bfail((s), MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+
+static int bam_reserve(mkt_bam* s, size_t need) {
+    if (need <= s->cap) return MKT_OK;
+    size_t ncap = s->cap ? s->cap : ((size_t)64 << 20);
+    while (ncap < need) ncap *= 2;
+    uint8_t* nb = nullptr;
+    BCHK(s, hipMalloc((void**)&nb, ncap + 64));
+    if (s->d_text) {
+        BCHK(s, hipStreamSynchronize(s->stream));
+        if (s->len) BCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice));
+        BCHK(s, hipFree(s->d_text));
+    }
+    s->d_text = nb; s->cap = ncap;
+    return MKT_OK;
+}
+static void crc_tables(CrcTabs* ct) {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0xEDB88320u : c >> 1;
+        ct->t[i] = c;
+    }
+    auto mul = [](uint32_t a, uint32_t b) {
+        uint32_t m = 1u << 31, p = 0;
+        for (;;) {
+            if (a & m) { p ^= b; if ((a & (m - 1u)) == 0u) break; }
+            m >>= 1;
+            b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+        }
+        return p;
+    };
+    uint32_t p = 1u << 30;                              // x^1
+    ct->x2n[0] = p;
+    for (int k = 1; k < 32; ++k) { p = mul(p, p); ct->x2n[k] = p; }
+}
+static void put_le32(std::string& s, uint32_t v) { char b[4] = {(char)v, (char)(v >> 8), (char)(v >> 16), (char)(v >> 24)}; s.append(b, 4); }
+static void put_le64(std::string& s, uint64_t v) { put_le32(s, (uint32_t)v); put_le32(s, (uint32_t)(v >> 32)); }
+
+extern "C" {
+
+int mkt_bam_create(int device, mkt_bam** out) {
+    if (!out) return MKT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MKT_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return MKT_E_ARG;
+    mkt_bam* s = new mkt_bam();
+    s->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return MKT_E_HIP; }
+    *out = s;
+    return MKT_OK;
+}
+void mkt_bam_destroy(mkt_bam* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_text) (void)hipFree(s->d_text);
+    if (s->d_bam) (void)hipFree(s->d_bam);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+const char* mkt_bam_error(const mkt_bam* s) { return s ? s->err.c_str() : ""; }
+
+// The next bytes of the SAM stream (any chunking).  Leading '@' lines are the header; everything from the first other line on
+// is alignment text and goes to the device.
+int mkt_bam_add(mkt_bam* s, const char* bytes, size_t n) {
+    if (!s || (n && !bytes)) return MKT_E_ARG;
+    if (s->ran) return bfail(s, MKT_E_STATE, "add after run");
+    BCHK(s, hipSetDevice(s->device));
+    size_t at = 0;
+    if (!s->header_done) {
+        s->pending.append(bytes, n);
+        size_t p = 0;
+        for (;;) {
+            if (p >= s->pending.size()) break;
+            if (s->pending[p] != '@') { s->header_done = true; break; }
+            const size_t e = s->pending.find('\n', p);
+            if (e == std::string::npos) break;              // an unfinished header line: wait for more
+            s->header.append(s->pending, p, e + 1 - p);
+            p = e + 1;
+        }
+        s->pending.erase(0, p);
+        if (!s->header_done) return MKT_OK;
+        std::string rest;
+        rest.swap(s->pending);
+        if (rest.empty()) return MKT_OK;
+        int rc = bam_reserve(s, s->len + rest.size() + 1);
+        if (rc) return rc;
+        BCHK(s, hipMemcpy(s->d_text + s->len, rest.data(), rest.size(), hipMemcpyHostToDevice));
+        s->len += rest.size();
+        return MKT_OK;
+    }
+    int rc = bam_reserve(s, s->len + n + 1);
+    if (rc) return rc;
+    if (n - at) BCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes + at, n - at, hipMemcpyHostToDevice, s->stream));
+    BCHK(s, hipStreamSynchronize(s->stream));
+    s->len += n - at;
+    return MKT_OK;
+}
+// alignment lines that are already on the device (no header lines)
+int mkt_bam_add_device(mkt_bam* s, const void* d_bytes, size_t n) {
+    if (!s || (n && !d_bytes)) return MKT_E_ARG;
+    if (s->ran) return bfail(s, MKT_E_STATE, "add after run");
+    if (!s->pending.empty()) return bfail(s, MKT_E_STATE, "device text after an unfinished header line");
+    s->header_done = true;
+    BCHK(s, hipSetDevice(s->device));
+    int rc = bam_reserve(s, s->len + n + 1);
+    if (rc) return rc;
+    if (n) BCHK(s, hipMemcpyAsync(s->d_text + s->len, d_bytes, n, hipMemcpyDeviceToDevice, s->stream));
+    BCHK(s, hipStreamSynchronize(s->stream));
+    s->len += n;
+    return MKT_OK;
+}
+
+int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* bam_bytes, uint64_t* bai_bytes) {
+    if (!s) return MKT_E_ARG;
+    if (s->ran) return bfail(s, MKT_E_STATE, "run twice");
+    BCHK(s, hipSetDevice(s->device));
+    if (records) *records = 0;
+    if (bam_bytes) *bam_bytes = 0;
+    if (bai_bytes) *bai_bytes = 0;
+    s->ran = true;
+    if (!s->pending.empty()) {                                     // a last header line without newline, or a file of header lines only
+        if (s->pending[0] == '@') { s->header += s->pending; s->header += '\n'; s->pending.clear(); }
+    }
+    hipStream_t st = s->stream;
+    if (s->len) {
+        char last = 0;
+        BCHK(s, hipMemcpy(&last, s->d_text + s->len - 1, 1, hipMemcpyDeviceToHost));
+        if (last != '\n') { const char nl = '\n'; int rc = bam_reserve(s, s->len + 2); if (rc) return rc; BCHK(s, hipMemcpy(s->d_text + s->len, &nl, 1, hipMemcpyHostToDevice)); ++s->len; }
+    }
+    // ---- header: text (with @HD SO:coordinate when sorting) and the reference dictionary from @SQ
+    std::string text = s->header;
+    std::vector<std::string> names;
+    std::vector<uint32_t> lens;
+    {
+        size_t p = 0;
+        while (p < text.size()) {
+            size_t e = text.find('\n', p);
+            if (e == std::string::npos) e = text.size();
+            if (e - p >= 3 && text.compare(p, 3, "@SQ") == 0) {
+                std::string sn;
+                long long ln = -1;
+                size_t q = p;
+                while (q < e) {
+                    size_t f = text.find('\t', q);
+                    if (f == std::string::npos || f > e) f = e;
+                    if (f - q > 3 && text.compare(q, 3, "SN:") == 0) sn = text.substr(q + 3, f - q - 3);
+                    if (f - q > 3 && text.compare(q, 3, "LN:") == 0) ln = atoll(text.substr(q + 3, f - q - 3).c_str());
+                    q = f + 1;
+                }
+                if (sn.empty() || ln < 0 || ln > 0x7fffffffll) return bfail(s, MKT_E_ARG, "bad @SQ line in the header (SN / LN)");
+                names.push_back(sn); lens.push_back((uint32_t)ln);
+            }
+            p = e + 1;
+        }
+        if (sorted) {
+            if (text.compare(0, 3, "@HD") == 0) {
+                size_t e = text.find('\n');
+                if (e == std::string::npos) e = text.size();
+                std::string hd = text.substr(0, e), out;
+                size_t q = 0;
+                bool had = false;
+                while (q <= hd.size()) {
+                    size_t f = hd.find('\t', q);
+                    if (f == std::string::npos) f = hd.size();
+                    std::string fld = hd.substr(q, f - q);
+                    if (fld.compare(0, 3, "SO:") == 0) { fld = "SO:coordinate"; had = true; }
+                    if (fld.compare(0, 3, "GO:") != 0) { if (!out.empty()) out += '\t'; out += fld; }       // (a grouping claim does not survive a sort)
+                    q = f + 1;
+                }
+                if (!had) out += "\tSO:coordinate";
+                text = out + text.substr(e);
+            } else text = "@HD\tVN:1.6\tSO:coordinate\n" + text;
+        }
+    }
+    const uint32_t nref = (uint32_t)names.size();
+    std::string hdr;                                               // SAMv1 4.2: magic, l_text, text, n_ref, (l_name, name, l_ref)*
+    hdr.append("BAM\1", 4);
+    put_le32(hdr, (uint32_t)text.size());
+    hdr += text;
+    put_le32(hdr, nref);
+    for (uint32_t i = 0; i < nref; ++i) { put_le32(hdr, (uint32_t)names[i].size() + 1); hdr += names[i]; hdr += '\0'; put_le32(hdr, lens[i]); }
+    const uint64_t hdr_len = hdr.size();
+    // reference table for the device
+    uint32_t tcap = 64;
+    while (tcap < 4 * nref + 4) tcap <<= 1;
+    std::vector<unsigned long long> th(tcap, 0ull);
+    std::vector<int32_t> tidv(tcap, -1);
+    std::vector<uint32_t> noff(nref + 1, 0);
+    std::string blob;
+    for (uint32_t i = 0; i < nref; ++i) {
+        noff[i] = (uint32_t)blob.size(); blob += names[i];
+        unsigned long long h = 0xcbf29ce484222325ull;
+        for (unsigned char c : names[i]) { h ^= c; h *= 0x100000001b3ull; }
+        if (!h) h = 1;
+        uint32_t k = (uint32_t)(h >> 20) & (tcap - 1);
+        bool dup = false;
+        while (th[k]) { if (th[k] == h && names[(size_t)tidv[k]] == names[i]) { dup = true; break; } k = (k + 1) & (tcap - 1); }
+        if (dup) return bfail(s, MKT_E_ARG, "reference name %s twice in the header", names[i].c_str());
+        th[k] = h; tidv[k] = (int32_t)i;
+    }
+    noff[nref] = (uint32_t)blob.size();
+
+    std::vector<void*> owned;
+    auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); owned.clear(); };
+#define BALLOC(ptr, bytes_) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes_)); if (e_ != hipSuccess) { cleanup(); return bfail(s, MKT_E_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(bytes_), hipGetErrorString(e_)); } owned.push_back((void*)(ptr)); } while (0)
+#define BRUN(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return bfail(s, MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    auto drop = [&](void* p) { (void)hipFree(p); owned.erase(std::remove(owned.begin(), owned.end(), p), owned.end()); };
+    unsigned long long* d_th = nullptr; int32_t* d_tid = nullptr; uint32_t* d_noff = nullptr; uint8_t* d_blob = nullptr;
+    CrcTabs* d_ct = nullptr;
+    uint32_t* d_err = nullptr;
+    BALLOC(d_th, tcap * sizeof(unsigned long long));
+    BALLOC(d_tid, tcap * sizeof(int32_t));
+    BALLOC(d_noff, (nref + 1) * sizeof(uint32_t));
+    BALLOC(d_blob, blob.size() + 16);
+    BALLOC(d_ct, sizeof(CrcTabs));
+    BALLOC(d_err, 256);
+    CrcTabs ct;
+    crc_tables(&ct);
+    BRUN(hipMemcpyAsync(d_th, th.data(), tcap * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    BRUN(hipMemcpyAsync(d_tid, tidv.data(), tcap * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    BRUN(hipMemcpyAsync(d_noff, noff.data(), (nref + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if (!blob.empty()) BRUN(hipMemcpyAsync(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, st));
+    BRUN(hipMemcpyAsync(d_ct, &ct, sizeof ct, hipMemcpyHostToDevice, st));
+    BRUN(hipMemsetAsync(d_err, 0, 256, st));
+    BRUN(hipStreamSynchronize(st));
+    RefTab rt;
+    rt.hash = d_th; rt.id = d_tid; rt.name_off = d_noff; rt.names = d_blob; rt.mask = tcap - 1; rt.nref = nref;
+
+    // ---- lines, keys, order
+    uint64_t nl = 0;
+    uint64_t* d_starts = nullptr;
+    if (s->len) {
+        BRUN(sort_line_index(s->d_text, s->len, st, &d_starts, &nl));
+        owned.push_back(d_starts);
+    }
+    if (nl >= (1ull << 32) - 1) { cleanup(); return bfail(s, MKT_E_ARG, "%llu lines: records are indexed with 32 bits", (unsigned long long)nl); }
+    SortRec *rA = nullptr, *rB = nullptr;
+    uint32_t *d_size = nullptr, *d_hist = nullptr;
+    uint64_t* d_off = nullptr;
+    BamIdx* d_idx = nullptr;
+    uint8_t* d_raw = nullptr;
+    uint64_t total = 0;
+    const unsigned lgrid = (unsigned)((nl + 255) / 256);
+    if (nl) {
+        BALLOC(rA, (nl + 1) * sizeof(SortRec));
+        BALLOC(d_size, (nl + 1) * sizeof(uint32_t));
+        BALLOC(d_off, (nl + 2) * sizeof(uint64_t));
+        hipLaunchKernelGGL(k_bam_keys, dim3(lgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, nl, rt, rA, d_size, d_err);
+        if (sorted) {
+            BALLOC(rB, (nl + 1) * sizeof(SortRec));
+            BALLOC(d_hist, kSortHistBytes);
+            int tbits = 1;
+            while ((1ull << tbits) <= (uint64_t)nref) ++tbits;
+            sort_radix_passes(rA, rB, nl, d_hist, 1, 0, 33 + tbits, st);
+        }
+        uint32_t herr = 0;
+        BRUN(hipMemcpyAsync(&herr, d_err, sizeof herr, hipMemcpyDeviceToHost, st));
+        BRUN(hipStreamSynchronize(st));
+        if (herr) {
+            cleanup();
+            return bfail(s, MKT_E_ARG, "not SAM alignment text (error bits 0x%x: 1 fewer than 11 fields, 2 reference name not in the header, 4 number, 8 CIGAR, 16 optional field, 32 SEQ / QUAL lengths, 64 QNAME length)", herr);
+        }
+        hipLaunchKernelGGL(k_bam_sizes, dim3(lgrid), dim3(256), 0, st, (const SortRec*)rA, (const uint32_t*)d_size, nl, d_off);
+        BRUN(launch_exscan(d_off, nl, d_off + nl, st));
+        BRUN(hipMemcpyAsync(&total, d_off + nl, sizeof total, hipMemcpyDeviceToHost, st));
+        BRUN(hipStreamSynchronize(st));
+    }
+    const uint64_t nraw = hdr_len + total;
+    BALLOC(d_raw, nraw + 64);
+    BRUN(hipMemcpyAsync(d_raw, hdr.data(), hdr_len, hipMemcpyHostToDevice, st));
+    if (nl) {
+        BALLOC(d_idx, (nl + 1) * sizeof(BamIdx));
+        hipLaunchKernelGGL(k_bam_write, dim3(lgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, nl, rt, (const SortRec*)rA, (const uint64_t*)d_off, d_raw + hdr_len, d_idx, d_err);
+        BRUN(hipGetLastError());
+        BRUN(hipStreamSynchronize(st));
+        // the text and the sort records are no longer needed
+        drop(rA); if (rB) drop(rB); drop(d_size); drop(d_starts);
+        rA = rB = nullptr;
+    }
+    (void)hipFree(s->d_text); s->d_text = nullptr; s->cap = s->len = 0;
+
+    // ---- BGZF
+    const uint64_t nblocks = (nraw + BGZF_RAW - 1) / BGZF_RAW;
+    uint8_t* d_comp = nullptr;
+    uint64_t* d_csize = nullptr;
+    uint32_t* d_scratch = nullptr;
+    BALLOC(d_comp, nblocks * (uint64_t)BGZF_STRIDE + 64);
+    BALLOC(d_csize, (nblocks + 2) * sizeof(uint64_t));
+    if (level > 0) {
+        BALLOC(d_scratch, nblocks * 4ull * DZ_QWORDS * sizeof(uint32_t) + 64);
+        hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nblocks), dim3(BWG), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize, d_scratch);
+    } else {
+        hipLaunchKernelGGL(k_bgzf_stored, dim3((unsigned)nblocks), dim3(BWG), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize);
+    }
+    BRUN(hipGetLastError());
+    BRUN(launch_exscan(d_csize, nblocks, d_csize + nblocks, st));
+    uint64_t clen = 0;
+    BRUN(hipMemcpyAsync(&clen, d_csize + nblocks, sizeof clen, hipMemcpyDeviceToHost, st));
+    BRUN(hipStreamSynchronize(st));
+    drop(d_raw);
+    if (d_scratch) drop(d_scratch);
+    static const unsigned char eof_block[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    { hipError_t e_ = hipMalloc((void**)&s->d_bam, clen + 28 + 64); if (e_ != hipSuccess) { cleanup(); return bfail(s, MKT_E_NOMEM, "hipMalloc of the BAM failed: %s", hipGetErrorString(e_)); } }
+    hipLaunchKernelGGL(k_bgzf_pack, dim3((unsigned)nblocks), dim3(BWG), 0, st, (const uint8_t*)d_comp, (const uint64_t*)d_csize, nblocks, s->d_bam);
+    BRUN(hipMemcpyAsync(s->d_bam + clen, eof_block, 28, hipMemcpyHostToDevice, st));
+    BRUN(hipGetLastError());
+    BRUN(hipStreamSynchronize(st));
+    s->bam_len = clen + 28;
+    s->records = nl;
+    drop(d_comp);
+
+    // ---- BAI (coordinate order only)
+    s->bai.clear();
+    if (sorted) {
+        std::vector<uint64_t> lin_off(nref + 1, 0);
+        for (uint32_t i = 0; i < nref; ++i) lin_off[i + 1] = lin_off[i] + ((uint64_t)lens[i] >> 14) + 2;
+        const uint64_t nlin = lin_off[nref];
+        uint64_t* d_lin_off = nullptr;
+        unsigned long long *d_lin = nullptr, *d_nocoor = nullptr;
+        BaiRef* d_refs = nullptr;
+        BaiHead* d_heads = nullptr;
+        uint32_t* d_nheads = nullptr;
+        uint32_t heads_cap = (uint32_t)std::min<uint64_t>(nl + 1, 1u << 26);
+        std::vector<BaiRef> refs(nref);
+        std::vector<unsigned long long> lin(nlin);
+        std::vector<BaiHead> heads;
+        unsigned long long no_coor = 0;
+        std::vector<BaiRef> init(nref);
+        for (auto& r : init) { r.n_mapped = 0; r.n_unmapped = 0; r.beg = ~0ull; r.end = 0; }
+        BALLOC(d_lin_off, (nref + 1) * sizeof(uint64_t));
+        BALLOC(d_lin, (nlin + 1) * sizeof(unsigned long long));
+        BALLOC(d_refs, (nref + 1) * sizeof(BaiRef));
+        BALLOC(d_nheads, 256);
+        BALLOC(d_nocoor, 256);
+        BALLOC(d_heads, ((size_t)heads_cap + 1) * sizeof(BaiHead));
+        BRUN(hipMemcpyAsync(d_lin_off, lin_off.data(), (nref + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        BRUN(hipMemsetAsync(d_lin, 0xFF, (nlin + 1) * sizeof(unsigned long long), st));
+        if (nref) BRUN(hipMemcpyAsync(d_refs, init.data(), nref * sizeof(BaiRef), hipMemcpyHostToDevice, st));
+        BRUN(hipMemsetAsync(d_nheads, 0, 256, st));
+        BRUN(hipMemsetAsync(d_nocoor, 0, 256, st));
+        uint32_t nheads = 0;
+        if (nl) {
+            hipLaunchKernelGGL(k_bai, dim3(lgrid), dim3(256), 0, st, (const BamIdx*)d_idx, (const uint64_t*)d_off, nl, hdr_len, (const uint64_t*)d_csize, (const uint64_t*)d_lin_off, nref,
+                               d_lin, d_refs, d_heads, d_nheads, heads_cap, d_nocoor);
+            BRUN(hipGetLastError());
+        }
+        BRUN(hipMemcpyAsync(&nheads, d_nheads, sizeof nheads, hipMemcpyDeviceToHost, st));
+        BRUN(hipMemcpyAsync(&no_coor, d_nocoor, sizeof no_coor, hipMemcpyDeviceToHost, st));
+        if (nref) BRUN(hipMemcpyAsync(refs.data(), d_refs, nref * sizeof(BaiRef), hipMemcpyDeviceToHost, st));
+        if (nlin) BRUN(hipMemcpyAsync(lin.data(), d_lin, nlin * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        BRUN(hipStreamSynchronize(st));
+        if (nheads > heads_cap) { cleanup(); return bfail(s, MKT_E_CAPACITY, "more than %u index chunks", heads_cap); }
+        heads.resize(nheads);
+        if (nheads) BRUN(hipMemcpy(heads.data(), d_heads, (size_t)nheads * sizeof(BaiHead), hipMemcpyDeviceToHost));
+        std::sort(heads.begin(), heads.end(), [](const BaiHead& a, const BaiHead& b) { return a.r < b.r; });
+        // the end of a run of records in one bin = the start of the record after it
+        const uint64_t n_coor = nl - no_coor;
+        uint64_t off_end = 0;
+        std::vector<uint64_t> coff_tail;
+        {
+            // virtual offset of the first record without coordinates (or of the end of the data)
+            uint64_t uo = 0;
+            if (nl) BRUN(hipMemcpy(&uo, d_off + n_coor, sizeof uo, hipMemcpyDeviceToHost));
+            uo += hdr_len;
+            const uint64_t b = uo / BGZF_RAW;
+            uint64_t cb = 0;
+            BRUN(hipMemcpy(&cb, d_csize + b, sizeof cb, hipMemcpyDeviceToHost));
+            off_end = (cb << 16) | (uo - b * BGZF_RAW);
+        }
+        std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins(nref);
+        for (uint32_t i = 0; i < nheads; ++i) {
+            const uint64_t e = i + 1 < nheads ? heads[i + 1].voff : off_end;
+            bins[(size_t)heads[i].tid][heads[i].bin].emplace_back(heads[i].voff, e);
+        }
+        std::string& o = s->bai;                                    // SAMv1 5.2
+        o.append("BAI\1", 4);
+        put_le32(o, nref);
+        for (uint32_t t = 0; t < nref; ++t) {
+            const bool any = refs[t].n_mapped + refs[t].n_unmapped > 0;
+            put_le32(o, (uint32_t)bins[t].size() + (any ? 1u : 0u));
+            for (auto& kv : bins[t]) {
+                put_le32(o, kv.first);
+                put_le32(o, (uint32_t)kv.second.size());
+                for (auto& c : kv.second) { put_le64(o, c.first); put_le64(o, c.second); }
+            }
+            if (any) {                                              // the pseudo-bin: file range of the reference, mapped / unmapped counts
+                put_le32(o, 37450u); put_le32(o, 2u);
+                put_le64(o, refs[t].beg); put_le64(o, refs[t].end);
+                put_le64(o, refs[t].n_mapped); put_le64(o, refs[t].n_unmapped);
+            }
+            // linear index: up to the last window that a record touched; empty windows take the next one's offset
+            const uint64_t a = lin_off[t], b = lin_off[t + 1];
+            uint64_t last = a;
+            for (uint64_t k = a; k < b; ++k) if (lin[k] != ~0ull) last = k + 1;
+            unsigned long long nextv = 0;
+            for (uint64_t k = last; k > a;) { --k; if (lin[k] == ~0ull) lin[k] = nextv; else nextv = lin[k]; }
+            put_le32(o, (uint32_t)(last - a));
+            for (uint64_t k = a; k < last; ++k) put_le64(o, lin[k]);
+        }
+        put_le64(o, no_coor);
+    }
+    cleanup();
+#undef BALLOC
+#undef BRUN
+    if (records) *records = s->records;
+    if (bam_bytes) *bam_bytes = s->bam_len;
+    if (bai_bytes) *bai_bytes = s->bai.size();
+    return MKT_OK;
+}
+
+int mkt_bam_fetch(mkt_bam* s, int which, uint64_t off, char* out, size_t n) {
+    if (!s || (n && !out)) return MKT_E_ARG;
+    if (!s->ran) return bfail(s, MKT_E_STATE, "fetch before run");
+    if (which == 1) {
+        if (off + n > s->bai.size()) return bfail(s, MKT_E_ARG, "range past the end of the index");
+        memcpy(out, s->bai.data() + off, n);
+        return MKT_OK;
+    }
+    if (off + n > s->bam_len) return bfail(s, MKT_E_ARG, "range past the end of the BAM");
+    BCHK(s, hipSetDevice(s->device));
+    if (n) BCHK(s, hipMemcpy(out, s->d_bam + off, n, hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+}  // extern "C"

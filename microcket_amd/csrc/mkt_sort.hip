@@ -18,12 +18,13 @@
 
 #include "../../include/mkt.h"
 #include "mkt_launch.h"
+#include "mkt_sortlib.h"
 
 using namespace mkt;
 
 namespace mkt {
 
-struct SortRec { uint64_t hi; uint32_t lo; uint32_t idx; };      // hi: rank(chr1) << 48 | rank(chr2) << 32 | pos1 ; lo: pos2 ; idx: line
+// SortRec (mkt_sortlib.h) as the sorter fills it -- hi: rank(chr1) << 48 | rank(chr2) << 32 | pos1 ; lo: pos2 ; idx: line
 
 constexpr int SWG = 256;
 constexpr uint32_t SCHUNK = 1u << 16;                             // text bytes per workgroup in the newline passes
@@ -280,6 +281,43 @@ __global__ __launch_bounds__(SWG) void k_out_copy(const SortRec* rec, uint64_t n
         const uint32_t len = (uint32_t)(starts[i + 1] - s);
         uint8_t* d = out + o0 + loff[j - b];
         for (uint32_t k = sub; k < len; k += 16) d[k] = text[s + k];
+    }
+}
+
+// ---- the same steps for other users (mkt_sortlib.h) ----------------------------------------------------------------
+hipError_t sort_line_index(const uint8_t* d_text, uint64_t n, hipStream_t st, uint64_t** d_starts, uint64_t* nlines) {
+    *d_starts = nullptr; *nlines = 0;
+    const uint32_t chunks = (uint32_t)((n + SCHUNK - 1) / SCHUNK);
+    uint64_t* d_cnt = nullptr;
+    hipError_t e = hipMalloc((void**)&d_cnt, ((size_t)chunks + 2) * sizeof(uint64_t));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_nl_count, dim3(chunks), dim3(SWG), 0, st, d_text, n, d_cnt);
+    uint64_t nl = 0;
+    e = launch_exscan(d_cnt, chunks, d_cnt + chunks, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nl, d_cnt + chunks, sizeof nl, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    uint64_t* d_st = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&d_st, (nl + 2) * sizeof(uint64_t));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_nl_starts, dim3(chunks), dim3(SWG), 0, st, d_text, n, (const uint64_t*)d_cnt, d_st);
+        e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d_cnt);
+    if (e != hipSuccess) { if (d_st) (void)hipFree(d_st); return e; }
+    *d_starts = d_st; *nlines = nl;
+    return hipSuccess;
+}
+void sort_radix_passes(SortRec*& rA, SortRec*& rB, uint64_t n, uint32_t* d_hist, int which, int lo_bit, int nbits, hipStream_t st) {
+    if (n == 0) return;
+    uint32_t G = (uint32_t)((n + 8191) / 8192);
+    if (G > 1024) G = 1024;
+    if (G == 0) G = 1;
+    const uint64_t per = (n + G - 1) / G;
+    for (int sh = 0; sh < nbits; sh += 4) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, n, per, which, lo_bit + sh, d_hist, G);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(SWG), 0, st, d_hist, 16u * G);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, n, per, which, lo_bit + sh, (const uint32_t*)d_hist, G, rB);
+        std::swap(rA, rB);
     }
 }
 
