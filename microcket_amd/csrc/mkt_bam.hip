@@ -20,8 +20,10 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -80,6 +82,22 @@ __device__ inline uint32_t reg2bin(int64_t beg, int64_t end) {        // SAMv1 5
 __device__ inline void put8(uint8_t*& o, uint32_t v) { *o++ = (uint8_t)v; }
 __device__ inline void put16(uint8_t*& o, uint32_t v) { o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o += 2; }
 __device__ inline void put32(uint8_t*& o, uint32_t v) { o[0] = (uint8_t)v; o[1] = (uint8_t)(v >> 8); o[2] = (uint8_t)(v >> 16); o[3] = (uint8_t)(v >> 24); o += 4; }
+// A record's bytes go out through this: single bytes up to the first 8-byte boundary, then whole aligned 8-byte words, single
+// bytes for the rest (the neighbours on both sides belong to other threads' records).
+struct Sink {
+    uint8_t* p;            // where the next stored byte goes (8-aligned whenever k > 0)
+    uint64_t acc;
+    uint32_t k;            // bytes waiting in acc
+    __device__ explicit Sink(uint8_t* at) : p(at), acc(0), k(0) {}
+    __device__ inline void b(uint32_t v) {
+        if (k == 0u && ((uintptr_t)p & 7u)) { *p++ = (uint8_t)v; return; }
+        acc |= (uint64_t)(v & 0xFFu) << (8u * k);
+        if (++k == 8u) { *reinterpret_cast<uint64_t*>(p) = acc; p += 8; acc = 0; k = 0; }
+    }
+    __device__ inline void h(uint32_t v) { b(v); b(v >> 8); }
+    __device__ inline void w(uint32_t v) { b(v); b(v >> 8); b(v >> 16); b(v >> 24); }
+    __device__ inline void flush() { for (uint32_t i = 0; i < k; ++i) p[i] = (uint8_t)(acc >> (8u * i)); p += k; k = 0; acc = 0; }
+};
 
 // unsigned decimal in [a, b); *ok cleared when it is not one
 __device__ inline uint64_t dec_u(const uint8_t* t, uint64_t a, uint64_t b, bool* ok) {
@@ -201,35 +219,34 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
     int64_t span = ((flag & 4u) || rlen == 0) ? 1 : rlen;
     const int64_t end = (int64_t)pos + span;
     const uint32_t bin = reg2bin(pos, end);
-    uint8_t* o = out;
+    Sink o(WRITE ? out + 4 : out);                             // block_size (the first four bytes) is written at the end
     if (WRITE) {
-        o += 4;                                                // block_size: at the end
-        put32(o, (uint32_t)tid);
-        put32(o, (uint32_t)pos);
-        put8(o, (uint32_t)l_qname + 1u);
-        put8(o, (uint32_t)mapq);
-        put16(o, bin);
-        put16(o, n_cigar);
-        put16(o, (uint32_t)flag);
-        put32(o, l_seq);
-        put32(o, (uint32_t)mtid);
-        put32(o, (uint32_t)((int32_t)pnext1 - 1));
-        put32(o, (uint32_t)(int32_t)tlen);
-        for (uint64_t p = ls; p < tab[0]; ++p) *o++ = t[p];
-        *o++ = 0;
+        o.w((uint32_t)tid);
+        o.w((uint32_t)pos);
+        o.b((uint32_t)l_qname + 1u);
+        o.b((uint32_t)mapq);
+        o.h(bin);
+        o.h(n_cigar);
+        o.h((uint32_t)flag);
+        o.w(l_seq);
+        o.w((uint32_t)mtid);
+        o.w((uint32_t)((int32_t)pnext1 - 1));
+        o.w((uint32_t)(int32_t)tlen);
+        for (uint64_t p = ls; p < tab[0]; ++p) o.b(t[p]);
+        o.b(0);
         if (!no_cigar) {
             uint32_t v = 0;
             for (uint64_t p = ca; p < cb; ++p) {
                 const uint32_t d = (uint32_t)t[p] - 48u;
                 if (d <= 9u) { v = v * 10 + d; continue; }
-                put32(o, (v << 4) | (uint32_t)cigar_op(t[p]));
+                o.w((v << 4) | (uint32_t)cigar_op(t[p]));
                 v = 0;
             }
         }
-        for (uint32_t k = 0; k + 1 < l_seq; k += 2) *o++ = (uint8_t)((seq_code(t[sa + k]) << 4) | seq_code(t[sa + k + 1]));
-        if (l_seq & 1u) *o++ = (uint8_t)(seq_code(t[sa + l_seq - 1]) << 4);
-        if (no_qual) for (uint32_t k = 0; k < l_seq; ++k) *o++ = 0xFF;
-        else for (uint32_t k = 0; k < l_seq; ++k) *o++ = (uint8_t)(t[qa + k] - 33u);
+        for (uint32_t k = 0; k + 1 < l_seq; k += 2) o.b((seq_code(t[sa + k]) << 4) | seq_code(t[sa + k + 1]));
+        if (l_seq & 1u) o.b(seq_code(t[sa + l_seq - 1]) << 4);
+        if (no_qual) for (uint32_t k = 0; k < l_seq; ++k) o.b(0xFF);
+        else for (uint32_t k = 0; k < l_seq; ++k) o.b(t[qa + k] - 33u);
     }
     uint32_t size = 4 + 32 + (uint32_t)l_qname + 1 + 4 * n_cigar + (l_seq + 1) / 2 + l_seq;
     // optional fields  TG:T:value
@@ -240,12 +257,12 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
         if (q - p < 5 || t[p + 2] != ':' || t[p + 4] != ':') { atomicOr(err, (uint32_t)BE_TAG); return 0; }
         const uint8_t ty = t[p + 3];
         const uint64_t va = p + 5, vb = q;
-        if (WRITE) { *o++ = t[p]; *o++ = t[p + 1]; }
+        if (WRITE) { o.b(t[p]); o.b(t[p + 1]); }
         size += 2;
         bool tok = true;
         if (ty == 'A' || ty == 'a' || ty == 'c' || ty == 'C') {      // (htslib reads the lower-case forms of the BAM types as A)
             if (vb - va != 1) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
-            if (WRITE) { *o++ = 'A'; *o++ = t[va]; }
+            if (WRITE) { o.b('A'); o.b(t[va]); }
             size += 2;
         } else if (ty == 'i' || ty == 'I') {
             const bool neg = va < vb && t[va] == '-';
@@ -254,15 +271,15 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
             char c; uint32_t w;
             if (neg) { if (x >= -128) { c = 'c'; w = 1; } else if (x >= -32768) { c = 's'; w = 2; } else { c = 'i'; w = 4; } }
             else { if (x <= 255) { c = 'C'; w = 1; } else if (x <= 65535) { c = 'S'; w = 2; } else { c = 'I'; w = 4; } }
-            if (WRITE) { *o++ = (uint8_t)c; if (w == 1) put8(o, (uint32_t)x); else if (w == 2) put16(o, (uint32_t)x); else put32(o, (uint32_t)x); }
+            if (WRITE) { o.b((uint8_t)c); if (w == 1) o.b((uint32_t)x); else if (w == 2) o.h((uint32_t)x); else o.w((uint32_t)x); }
             size += 1 + w;
         } else if (ty == 'f') {
             const float f = dec_f(t, va, vb, &tok);
             if (!tok) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
-            if (WRITE) { *o++ = 'f'; put32(o, __float_as_uint(f)); }
+            if (WRITE) { o.b('f'); o.w(__float_as_uint(f)); }
             size += 5;
         } else if (ty == 'Z' || ty == 'H') {
-            if (WRITE) { *o++ = ty; for (uint64_t k = va; k < vb; ++k) *o++ = t[k]; *o++ = 0; }
+            if (WRITE) { o.b(ty); for (uint64_t k = va; k < vb; ++k) o.b(t[k]); o.b(0); }
             size += 2 + (uint32_t)(vb - va);
         } else if (ty == 'B') {
             if (va >= vb) { atomicOr(err, (uint32_t)BE_TAG); return 0; }
@@ -274,13 +291,13 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
             for (uint64_t k = va + 1; k < vb; ++k) if (t[k] == ',') ++cnt;
             if (va + 1 < vb && t[va + 1] != ',') { atomicOr(err, (uint32_t)BE_TAG); return 0; }
             if (WRITE) {
-                *o++ = 'B'; *o++ = sub; put32(o, cnt);
+                o.b('B'); o.b(sub); o.w(cnt);
                 uint64_t k = va + 2;
                 for (uint32_t i = 0; i < cnt; ++i) {
                     uint64_t e = k;
                     while (e < vb && t[e] != ',') ++e;
-                    if (sub == 'f') put32(o, __float_as_uint(dec_f(t, k, e, &tok)));
-                    else { const int64_t x = dec_s(t, k, e, &tok); if (w == 1) put8(o, (uint32_t)x); else if (w == 2) put16(o, (uint32_t)x); else put32(o, (uint32_t)x); }
+                    if (sub == 'f') o.w(__float_as_uint(dec_f(t, k, e, &tok)));
+                    else { const int64_t x = dec_s(t, k, e, &tok); if (w == 1) o.b((uint32_t)x); else if (w == 2) o.h((uint32_t)x); else o.w((uint32_t)x); }
                     k = e + 1;
                 }
             } else {
@@ -297,7 +314,7 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
         } else { atomicOr(err, (uint32_t)BE_TAG); return 0; }
         p = q + 1;
     }
-    if (WRITE) { uint8_t* h = out; put32(h, size - 4); }
+    if (WRITE) { o.flush(); uint8_t* h = out; put32(h, size - 4); }
     if (ix) { ix->tid = tid; ix->beg = pos; ix->end = (int32_t)(end > 0x7fffffffll ? 0x7fffffffll : end); ix->bin = bin | ((uint32_t)flag << 16); }
     return size;
 }
@@ -449,18 +466,37 @@ __device__ inline void dist_code(uint32_t dist, uint32_t& sym, uint32_t& eb, uin
 }
 
 __global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64_t nraw, const CrcTabs* ct, uint8_t* comp, uint64_t* csize, uint32_t* scratch /* per block 4 * DZ_QWORDS */) {
-    __shared__ uint8_t in[BGZF_RAW + 16];
+    __shared__ __attribute__((aligned(16))) uint32_t in32[(BGZF_RAW + 16) / 4];
     __shared__ uint32_t htab[4][1u << DZ_HBITS];
     __shared__ uint32_t stage_[4][80];                    // one step's bits of a wave: 64 tokens of <= 31 bits + the carry
     __shared__ uint32_t tabl[256], x2n[32], sh[BWG / 64];
     __shared__ uint32_t wbits[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint8_t* in = reinterpret_cast<uint8_t*>(in32);
+    auto word_at = [&](uint32_t off) {                   // the four bytes at any offset (two aligned reads)
+        const uint32_t i = off >> 2;
+        return __builtin_amdgcn_alignbyte(in32[i + 1], in32[i], off & 3u);
+    };
+    auto match_len = [&](uint32_t c, uint32_t p, uint32_t lim) {
+        uint32_t l = 0;
+        while (l < lim) {
+            const uint32_t x = word_at(c + l) ^ word_at(p + l);
+            if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
+            l += 4;
+        }
+        return l < lim ? l : lim;
+    };
     volatile uint32_t (*stage)[80] = stage_;             // lanes of a wave hand bits to each other through it
     tabl[tid] = ct->t[tid];
     if (tid < 32) x2n[tid] = ct->x2n[tid];
     const uint64_t b0 = (uint64_t)blockIdx.x * BGZF_RAW;
     const uint32_t n = (uint32_t)(nraw - b0 < BGZF_RAW ? nraw - b0 : BGZF_RAW);
-    for (uint32_t i = tid; i < BGZF_RAW + 16; i += BWG) in[i] = i < n ? raw[b0 + i] : 0;
+    {   // the block into LDS, 16 bytes per load (blocks start on multiples of 16; the raw buffer is readable 64 bytes past its end,
+        // and what lies behind byte n is never looked at)
+        const uint4* src = reinterpret_cast<const uint4*>(raw + b0);
+        uint4* dst = reinterpret_cast<uint4*>(in32);
+        for (uint32_t i = tid; i < (BGZF_RAW + 16) / 16; i += BWG) dst[i] = (i << 4) < n ? src[i] : make_uint4(0, 0, 0, 0);
+    }
     for (uint32_t i = lane; i < (1u << DZ_HBITS); i += 64) htab[wv][i] = 0;          // 0 = empty (positions are stored + 1)
     __syncthreads();
     const uint32_t crc = block_crc(in, n, tabl, x2n, sh);
@@ -478,20 +514,19 @@ __global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64
         uint32_t mlen = 0, mdist = 0;
         uint32_t h = 0;
         const bool hashable = live && p + DZ_MINLEN <= q1;
+        const bool open_step = cur < base + 64u;          // (uniform) false: a match from an earlier step covers all 64 positions
         if (hashable) {
-            const uint32_t v = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+            const uint32_t v = word_at(p);
             h = (v * 2654435761u) >> (32 - DZ_HBITS);
             const uint32_t c1 = htab[wv][h];
             const uint32_t lim = q1 - p < DZ_MAXLEN ? q1 - p : DZ_MAXLEN;
-            if (c1) {
+            if (open_step && c1) {
                 const uint32_t c = c1 - 1;               // < base: only earlier steps have written
-                uint32_t l = 0;
-                while (l < lim && in[c + l] == in[p + l]) ++l;
+                const uint32_t l = match_len(c, p, lim);
                 if (l >= DZ_MINLEN) { mlen = l; mdist = p - c; }
             }
-            if (p > q0 && mlen < lim) {                  // runs: distance 1
-                uint32_t l = 0;
-                while (l < lim && in[p - 1 + l] == in[p + l]) ++l;
+            if (open_step && p > q0 && mlen < lim && in[p - 1] == in[p]) {       // runs: distance 1
+                const uint32_t l = match_len(p - 1, p, lim);
                 if (l >= DZ_MINLEN && l > mlen) { mlen = l; mdist = 1; }
             }
         }
@@ -635,27 +670,67 @@ __device__ inline uint64_t voffset(uint64_t uoff, const uint64_t* coff) {
     return (coff[b] << 16) | (uoff - b * BGZF_RAW);
 }
 __global__ void k_bai(const BamIdx* idx, const uint64_t* off /* [n + 1] */, uint64_t n, uint64_t hdr_len, const uint64_t* coff, const uint64_t* lin_off, uint32_t nref,
-                      unsigned long long* lin, BaiRef* refs, BaiHead* heads, uint32_t* nheads, uint32_t heads_cap, unsigned long long* no_coor) {
+                      unsigned long long* lin, BaiRef* refs, uint64_t* head_flag /* [n]: 1 where a run of records in one bin starts */, unsigned long long* no_coor) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    const BamIdx x = idx[r];
-    if (x.tid < 0) { atomicAdd(no_coor, 1ull); return; }
-    const uint64_t v0 = voffset(hdr_len + off[r], coff), v1 = voffset(hdr_len + off[r + 1], coff);
+    if (r < n) head_flag[r] = 0;
+    const int lane = threadIdx.x & 63;
+    BamIdx x;
+    x.tid = -1; x.beg = 0; x.end = 0; x.bin = 0;
+    if (r < n) x = idx[r];
+    const bool placed = r < n && x.tid >= 0;
+    const uint64_t nc = __ballot(r < n && x.tid < 0);
+    if (nc && lane == (int)__builtin_ctzll(nc)) atomicAdd(no_coor, (unsigned long long)__popcll(nc));
+    const uint64_t pm = __ballot(placed);
+    if (!pm) return;
+    uint64_t v0 = 0, v1 = 0;
+    if (placed) { v0 = voffset(hdr_len + off[r], coff); v1 = voffset(hdr_len + off[r + 1], coff); }
     const uint32_t bin = x.bin & 0xFFFFu;
-    BaiRef* R = &refs[x.tid];
-    if ((x.bin >> 18) & 1u) atomicAdd(&R->n_unmapped, 1ull); else atomicAdd(&R->n_mapped, 1ull);       // FLAG 0x4
-    atomicMin(&R->beg, (unsigned long long)v0);
-    atomicMax(&R->end, (unsigned long long)v1);
+    const bool unm = (x.bin >> 18) & 1u;                           // FLAG 0x4
+    // per-reference counts and file range: the records are sorted, so a wave nearly always holds ONE reference -> one set of atomics
+    const int first = (int)__builtin_ctzll(pm);
+    const int32_t tid0 = __shfl(x.tid, first, 64);
+    if (__ballot(placed && x.tid == tid0) == pm) {
+        const uint32_t cu = (uint32_t)__popcll(__ballot(placed && unm)), cm = (uint32_t)__popcll(pm) - cu;
+        uint64_t lo = placed ? v0 : ~0ull, hi = placed ? v1 : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const uint64_t a = (uint64_t)__shfl_xor((long long)lo, d, 64), b = (uint64_t)__shfl_xor((long long)hi, d, 64);
+            lo = a < lo ? a : lo; hi = b > hi ? b : hi;
+        }
+        if (lane == first) {
+            BaiRef* R = &refs[tid0];
+            if (cm) atomicAdd(&R->n_mapped, (unsigned long long)cm);
+            if (cu) atomicAdd(&R->n_unmapped, (unsigned long long)cu);
+            atomicMin(&R->beg, (unsigned long long)lo);
+            atomicMax(&R->end, (unsigned long long)hi);
+        }
+    } else if (placed) {
+        BaiRef* R = &refs[x.tid];
+        if (unm) atomicAdd(&R->n_unmapped, 1ull); else atomicAdd(&R->n_mapped, 1ull);
+        atomicMin(&R->beg, (unsigned long long)v0);
+        atomicMax(&R->end, (unsigned long long)v1);
+    }
+    if (!placed) return;
     const uint64_t nwin = lin_off[x.tid + 1] - lin_off[x.tid];
     int64_t w0 = x.beg < 0 ? 0 : (x.beg >> 14), w1 = (x.end > 0 ? x.end - 1 : 0) >> 14;
     if (w1 < w0) w1 = w0;
     for (int64_t w = w0; w <= w1 && (uint64_t)w < nwin; ++w) atomicMin(&lin[lin_off[x.tid] + (uint64_t)w], (unsigned long long)v0);
     bool head = r == 0;
     if (!head) { const BamIdx y = idx[r - 1]; head = y.tid != x.tid || (y.bin & 0xFFFFu) != bin; }
-    if (head) {
-        const uint32_t k = atomicAdd(nheads, 1u);
-        if (k < heads_cap) { BaiHead h; h.r = (uint32_t)r; h.tid = x.tid; h.bin = bin; h.pad = 0; h.voff = v0; heads[k] = h; }
-    }
+    if (head) head_flag[r] = 1;
+}
+// the run starts, in file order (head_pos = exclusive scan of head_flag)
+__global__ void k_bai_heads(const BamIdx* idx, const uint64_t* off, uint64_t n, uint64_t hdr_len, const uint64_t* coff, const uint64_t* head_pos, BaiHead* heads) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const BamIdx x = idx[r];
+    if (x.tid < 0) return;
+    bool head = r == 0;
+    if (!head) { const BamIdx y = idx[r - 1]; head = y.tid != x.tid || ((y.bin ^ x.bin) & 0xFFFFu) != 0u; }
+    if (!head) return;
+    BaiHead h;
+    h.r = (uint32_t)r; h.tid = x.tid; h.bin = x.bin & 0xFFFFu; h.pad = 0; h.voff = voffset(hdr_len + off[r], coff);
+    heads[head_pos[r]] = h;
 }
 
 }  // namespace mkt
@@ -807,6 +882,14 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         if (s->pending[0] == '@') { s->header += s->pending; s->header += '\n'; s->pending.clear(); }
     }
     hipStream_t st = s->stream;
+    const bool verbose = getenv("MKT_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {                            // (call sites follow a stream synchronisation)
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mkt_bam] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (s->len) {
         char last = 0;
         BCHK(s, hipMemcpy(&last, s->d_text + s->len - 1, 1, hipMemcpyDeviceToHost));
@@ -918,6 +1001,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         BRUN(sort_line_index(s->d_text, s->len, st, &d_starts, &nl));
         owned.push_back(d_starts);
     }
+    mark("header + line index");
     if (nl >= (1ull << 32) - 1) { cleanup(); return bfail(s, MKT_E_ARG, "%llu lines: records are indexed with 32 bits", (unsigned long long)nl); }
     SortRec *rA = nullptr, *rB = nullptr;
     uint32_t *d_size = nullptr, *d_hist = nullptr;
@@ -945,6 +1029,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
             cleanup();
             return bfail(s, MKT_E_ARG, "not SAM alignment text (error bits 0x%x: 1 fewer than 11 fields, 2 reference name not in the header, 4 number, 8 CIGAR, 16 optional field, 32 SEQ / QUAL lengths, 64 QNAME length)", herr);
         }
+        mark(sorted ? "keys + radix sort" : "keys");
         hipLaunchKernelGGL(k_bam_sizes, dim3(lgrid), dim3(256), 0, st, (const SortRec*)rA, (const uint32_t*)d_size, nl, d_off);
         BRUN(launch_exscan(d_off, nl, d_off + nl, st));
         BRUN(hipMemcpyAsync(&total, d_off + nl, sizeof total, hipMemcpyDeviceToHost, st));
@@ -958,6 +1043,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         hipLaunchKernelGGL(k_bam_write, dim3(lgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, nl, rt, (const SortRec*)rA, (const uint64_t*)d_off, d_raw + hdr_len, d_idx, d_err);
         BRUN(hipGetLastError());
         BRUN(hipStreamSynchronize(st));
+        mark("records");
         // the text and the sort records are no longer needed
         drop(rA); if (rB) drop(rB); drop(d_size); drop(d_starts);
         rA = rB = nullptr;
@@ -982,6 +1068,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
     uint64_t clen = 0;
     BRUN(hipMemcpyAsync(&clen, d_csize + nblocks, sizeof clen, hipMemcpyDeviceToHost, st));
     BRUN(hipStreamSynchronize(st));
+    mark(level > 0 ? "BGZF deflate" : "BGZF stored");
     drop(d_raw);
     if (d_scratch) drop(d_scratch);
     static const unsigned char eof_block[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0, 0x42, 0x43, 0x02, 0, 0x1b, 0, 0x03, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -993,6 +1080,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
     s->bam_len = clen + 28;
     s->records = nl;
     drop(d_comp);
+    mark("pack");
 
     // ---- BAI (coordinate order only)
     s->bai.clear();
@@ -1004,8 +1092,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         unsigned long long *d_lin = nullptr, *d_nocoor = nullptr;
         BaiRef* d_refs = nullptr;
         BaiHead* d_heads = nullptr;
-        uint32_t* d_nheads = nullptr;
-        uint32_t heads_cap = (uint32_t)std::min<uint64_t>(nl + 1, 1u << 26);
+        uint64_t* d_hflag = nullptr;
         std::vector<BaiRef> refs(nref);
         std::vector<unsigned long long> lin(nlin);
         std::vector<BaiHead> heads;
@@ -1015,33 +1102,35 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         BALLOC(d_lin_off, (nref + 1) * sizeof(uint64_t));
         BALLOC(d_lin, (nlin + 1) * sizeof(unsigned long long));
         BALLOC(d_refs, (nref + 1) * sizeof(BaiRef));
-        BALLOC(d_nheads, 256);
         BALLOC(d_nocoor, 256);
-        BALLOC(d_heads, ((size_t)heads_cap + 1) * sizeof(BaiHead));
+        BALLOC(d_hflag, (nl + 2) * sizeof(uint64_t));
         BRUN(hipMemcpyAsync(d_lin_off, lin_off.data(), (nref + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         BRUN(hipMemsetAsync(d_lin, 0xFF, (nlin + 1) * sizeof(unsigned long long), st));
         if (nref) BRUN(hipMemcpyAsync(d_refs, init.data(), nref * sizeof(BaiRef), hipMemcpyHostToDevice, st));
-        BRUN(hipMemsetAsync(d_nheads, 0, 256, st));
         BRUN(hipMemsetAsync(d_nocoor, 0, 256, st));
-        uint32_t nheads = 0;
+        uint64_t nheads = 0;
         if (nl) {
             hipLaunchKernelGGL(k_bai, dim3(lgrid), dim3(256), 0, st, (const BamIdx*)d_idx, (const uint64_t*)d_off, nl, hdr_len, (const uint64_t*)d_csize, (const uint64_t*)d_lin_off, nref,
-                               d_lin, d_refs, d_heads, d_nheads, heads_cap, d_nocoor);
+                               d_lin, d_refs, d_hflag, d_nocoor);
             BRUN(hipGetLastError());
+            BRUN(launch_exscan(d_hflag, nl, d_hflag + nl, st));
+            BRUN(hipMemcpyAsync(&nheads, d_hflag + nl, sizeof nheads, hipMemcpyDeviceToHost, st));
         }
-        BRUN(hipMemcpyAsync(&nheads, d_nheads, sizeof nheads, hipMemcpyDeviceToHost, st));
         BRUN(hipMemcpyAsync(&no_coor, d_nocoor, sizeof no_coor, hipMemcpyDeviceToHost, st));
         if (nref) BRUN(hipMemcpyAsync(refs.data(), d_refs, nref * sizeof(BaiRef), hipMemcpyDeviceToHost, st));
         if (nlin) BRUN(hipMemcpyAsync(lin.data(), d_lin, nlin * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BRUN(hipStreamSynchronize(st));
-        if (nheads > heads_cap) { cleanup(); return bfail(s, MKT_E_CAPACITY, "more than %u index chunks", heads_cap); }
         heads.resize(nheads);
-        if (nheads) BRUN(hipMemcpy(heads.data(), d_heads, (size_t)nheads * sizeof(BaiHead), hipMemcpyDeviceToHost));
-        std::sort(heads.begin(), heads.end(), [](const BaiHead& a, const BaiHead& b) { return a.r < b.r; });
+        if (nheads) {
+            BALLOC(d_heads, ((size_t)nheads + 1) * sizeof(BaiHead));
+            hipLaunchKernelGGL(k_bai_heads, dim3(lgrid), dim3(256), 0, st, (const BamIdx*)d_idx, (const uint64_t*)d_off, nl, hdr_len, (const uint64_t*)d_csize, (const uint64_t*)d_hflag, d_heads);
+            BRUN(hipGetLastError());
+            BRUN(hipMemcpyAsync(heads.data(), d_heads, (size_t)nheads * sizeof(BaiHead), hipMemcpyDeviceToHost, st));
+            BRUN(hipStreamSynchronize(st));
+        }
         // the end of a run of records in one bin = the start of the record after it
         const uint64_t n_coor = nl - no_coor;
         uint64_t off_end = 0;
-        std::vector<uint64_t> coff_tail;
         {
             // virtual offset of the first record without coordinates (or of the end of the data)
             uint64_t uo = 0;
@@ -1052,21 +1141,43 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
             BRUN(hipMemcpy(&cb, d_csize + b, sizeof cb, hipMemcpyDeviceToHost));
             off_end = (cb << 16) | (uo - b * BGZF_RAW);
         }
-        std::vector<std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>>> bins(nref);
-        for (uint32_t i = 0; i < nheads; ++i) {
-            const uint64_t e = i + 1 < nheads ? heads[i + 1].voff : off_end;
-            bins[(size_t)heads[i].tid][heads[i].bin].emplace_back(heads[i].voff, e);
+        // per reference (the run starts come in file order = by reference): a stable counting sort by bin
+        std::vector<uint32_t> bin_cnt(37452, 0), bin_at(37452, 0);
+        std::vector<uint32_t> order(nheads);
+        std::vector<std::pair<size_t, size_t>> ref_range(nref, {0, 0});
+        {
+            size_t i = 0;
+            for (uint32_t t = 0; t < nref && i < nheads; ++t) {
+                size_t j = i;
+                while (j < nheads && (uint32_t)heads[j].tid == t) ++j;
+                ref_range[t] = {i, j};
+                i = j;
+            }
         }
         std::string& o = s->bai;                                    // SAMv1 5.2
+        o.reserve(64 + (size_t)nheads * 28 + nlin * 8 + (size_t)nref * 64);
         o.append("BAI\1", 4);
         put_le32(o, nref);
         for (uint32_t t = 0; t < nref; ++t) {
             const bool any = refs[t].n_mapped + refs[t].n_unmapped > 0;
-            put_le32(o, (uint32_t)bins[t].size() + (any ? 1u : 0u));
-            for (auto& kv : bins[t]) {
-                put_le32(o, kv.first);
-                put_le32(o, (uint32_t)kv.second.size());
-                for (auto& c : kv.second) { put_le64(o, c.first); put_le64(o, c.second); }
+            const size_t i0 = ref_range[t].first, i1 = ref_range[t].second;
+            std::vector<uint32_t> used;                             // the bins of this reference, ascending
+            for (size_t i = i0; i < i1; ++i) if (bin_cnt[heads[i].bin]++ == 0) used.push_back(heads[i].bin);
+            std::sort(used.begin(), used.end());
+            uint32_t at = 0;
+            for (uint32_t b : used) { bin_at[b] = at; at += bin_cnt[b]; }
+            for (size_t i = i0; i < i1; ++i) order[i0 + bin_at[heads[i].bin]++] = (uint32_t)i;
+            put_le32(o, (uint32_t)used.size() + (any ? 1u : 0u));
+            size_t k = i0;
+            for (uint32_t b : used) {
+                put_le32(o, b);
+                put_le32(o, bin_cnt[b]);
+                for (uint32_t c = 0; c < bin_cnt[b]; ++c, ++k) {
+                    const size_t i = order[k];
+                    put_le64(o, heads[i].voff);
+                    put_le64(o, i + 1 < nheads ? heads[i + 1].voff : off_end);
+                }
+                bin_cnt[b] = 0;
             }
             if (any) {                                              // the pseudo-bin: file range of the reference, mapped / unmapped counts
                 put_le32(o, 37450u); put_le32(o, 2u);
@@ -1083,6 +1194,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
             for (uint64_t k = a; k < last; ++k) put_le64(o, lin[k]);
         }
         put_le64(o, no_coor);
+        mark("BAI");
     }
     cleanup();
 #undef BALLOC

@@ -1319,9 +1319,51 @@ hipError_t launch_synth_sizes(const SynParams& p, uint64_t first, uint64_t n, ui
     if (n) hipLaunchKernelGGL(k_synth_sizes, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, first, n, sizes);
     return hipGetLastError();
 }
+// long arrays (line tables of the sorter / krmdup / BAM writer): per-chunk sums, the single-workgroup scan over the sums, then the
+// chunks again with their offsets
+constexpr uint32_t XS_PER = 16 * NT;
+__global__ __launch_bounds__(NT) void k_xs_sums(const uint64_t* v, uint64_t n, uint64_t* part) {
+    __shared__ uint64_t sh[NT / 64];
+    const uint64_t b = (uint64_t)blockIdx.x * XS_PER;
+    uint64_t x = 0;
+    for (uint32_t k = 0; k < XS_PER / NT; ++k) { const uint64_t i = b + k * NT + threadIdx.x; if (i < n) x += v[i]; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += shfl_xor64(x, d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint64_t t = 0; for (int w = 0; w < NT / 64; ++w) t += sh[w]; part[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(NT) void k_xs_apply(uint64_t* v, uint64_t n, const uint64_t* part) {
+    __shared__ ScanScratch sc;
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = part[blockIdx.x];
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * XS_PER;
+    for (uint32_t k = 0; k < XS_PER / NT; ++k) {
+        const uint64_t i = b + k * NT + threadIdx.x;
+        uint64_t e = i < n ? v[i] : 0, d = 0, tx, td;
+        block_exscan2(e, d, tx, td, sc);
+        if (i < n) v[i] = carry + e;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tx;
+        __syncthreads();
+    }
+}
 hipError_t launch_exscan(uint64_t* v, uint64_t n, uint64_t* total, hipStream_t s) {
-    hipLaunchKernelGGL(k_exscan_u64, dim3(1), dim3(NT), 0, s, v, n, total);
-    return hipGetLastError();
+    if (n <= 4 * XS_PER) {
+        hipLaunchKernelGGL(k_exscan_u64, dim3(1), dim3(NT), 0, s, v, n, total);
+        return hipGetLastError();
+    }
+    const uint64_t nb = (n + XS_PER - 1) / XS_PER;
+    uint64_t* part = nullptr;
+    hipError_t e = hipMallocAsync((void**)&part, (nb + 1) * sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_xs_sums, dim3((unsigned)nb), dim3(NT), 0, s, (const uint64_t*)v, n, part);
+    hipLaunchKernelGGL(k_exscan_u64, dim3(1), dim3(NT), 0, s, part, nb, total);
+    hipLaunchKernelGGL(k_xs_apply, dim3((unsigned)nb), dim3(NT), 0, s, v, n, (const uint64_t*)part);
+    e = hipGetLastError();
+    const hipError_t e2 = hipFreeAsync(part, s);
+    return e != hipSuccess ? e : e2;
 }
 hipError_t launch_synth_write(const SynParams& p, uint64_t first, uint64_t n, const uint64_t* offs, char* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_synth_write, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, first, n, offs, out);

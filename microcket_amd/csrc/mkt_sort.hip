@@ -28,7 +28,6 @@ namespace mkt {
 
 constexpr int SWG = 256;
 constexpr uint32_t SCHUNK = 1u << 16;                             // text bytes per workgroup in the newline passes
-constexpr uint32_t SSPAN = SCHUNK / SWG;                          // ... and per thread (contiguous)
 enum { SE_FIELDS = 1, SE_NAME = 2, SE_RUN = 4 };
 
 __device__ inline uint32_t blk_exscan(uint32_t v, uint32_t* total, uint32_t* sh /* [SWG / 64] */) {
@@ -47,24 +46,58 @@ __device__ inline uint32_t blk_exscan(uint32_t v, uint32_t* total, uint32_t* sh 
 }
 
 // ---- line index ---------------------------------------------------------------------------------------------
+// A workgroup takes SCHUNK bytes, a wave a quarter of them in 16 rounds of 64 x 16 bytes (coalesced).  Per 16-byte vector an exact
+// newline mask (one bit per byte), counted here and turned into positions in k_nl_starts.  The text buffers are readable up to 64
+// bytes past their end (bytes at or past n are masked).
+__device__ inline uint32_t nl_mask16(const uint8_t* text, uint64_t off, uint64_t n) {
+    if (off >= n) return 0u;
+    const uint4 x = *reinterpret_cast<const uint4*>(text + off);
+    auto flags = [](uint32_t w) { const uint32_t y = w ^ 0x0A0A0A0Au, z = y & 0x7F7F7F7Fu; return ~((z + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); };   // 0x80 per '\n'
+    auto pack = [](uint32_t f) { return ((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u); };
+    uint32_t m = pack(flags(x.x)) | (pack(flags(x.y)) << 4) | (pack(flags(x.z)) << 8) | (pack(flags(x.w)) << 12);
+    if (n - off < 16u) m &= (1u << (uint32_t)(n - off)) - 1u;
+    return m;
+}
+constexpr uint32_t SWAVE = SCHUNK / (SWG / 64);                     // bytes per wave
+constexpr int SROUNDS = SWAVE / (64 * 16);
 __global__ __launch_bounds__(SWG) void k_nl_count(const uint8_t* text, uint64_t n, uint64_t* counts) {
     __shared__ uint32_t sh[SWG / 64];
-    const uint64_t b = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SSPAN;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t b = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)wv * SWAVE;
     uint32_t c = 0;
-    for (uint32_t k = 0; k < SSPAN; ++k) if (b + k < n && text[b + k] == '\n') ++c;
+#pragma unroll
+    for (int k = 0; k < SROUNDS; ++k) c += (uint32_t)__popc(nl_mask16(text, b + ((uint64_t)(k * 64 + lane) << 4), n));
     uint32_t tot;
     (void)blk_exscan(c, &tot, sh);
     if (threadIdx.x == 0) counts[blockIdx.x] = tot;
 }
 // starts[0] = 0, starts[r + 1] = (position of newline r) + 1: line k is text[starts[k], starts[k + 1]) with its newline
 __global__ __launch_bounds__(SWG) void k_nl_starts(const uint8_t* text, uint64_t n, const uint64_t* offs, uint64_t* starts) {
-    __shared__ uint32_t sh[SWG / 64];
-    const uint64_t b = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)threadIdx.x * SSPAN;
+    __shared__ uint32_t wtot[SWG / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t b = (uint64_t)blockIdx.x * SCHUNK + (uint64_t)wv * SWAVE;
+    uint32_t m[SROUNDS];
     uint32_t c = 0;
-    for (uint32_t k = 0; k < SSPAN; ++k) if (b + k < n && text[b + k] == '\n') ++c;
-    uint32_t tot;
-    uint64_t r = offs[blockIdx.x] + blk_exscan(c, &tot, sh);
-    for (uint32_t k = 0; k < SSPAN; ++k) if (b + k < n && text[b + k] == '\n') starts[++r] = b + k + 1;
+#pragma unroll
+    for (int k = 0; k < SROUNDS; ++k) { m[k] = nl_mask16(text, b + ((uint64_t)(k * 64 + lane) << 4), n); c += (uint32_t)__popc(m[k]); }
+    uint32_t w = c;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) w += (uint32_t)__shfl_xor((int)w, d, 64);
+    if (lane == 0) wtot[wv] = w;
+    __syncthreads();
+    uint64_t r = offs[blockIdx.x];
+    for (int v = 0; v < wv; ++v) r += wtot[v];
+#pragma unroll
+    for (int k = 0; k < SROUNDS; ++k) {
+        const uint32_t ck = (uint32_t)__popc(m[k]);
+        uint32_t inc = ck;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += y; }
+        uint64_t at = r + inc - ck;
+        const uint64_t p0 = b + ((uint64_t)(k * 64 + lane) << 4);
+        for (uint32_t mm = m[k]; mm; mm &= mm - 1u) starts[++at] = p0 + (uint32_t)__builtin_ctz(mm) + 1u;
+        r += (uint32_t)__shfl((int)inc, 63, 64);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) starts[0] = 0;
 }
 

@@ -13,6 +13,7 @@
 // Exit codes: 0 ok, 2 usage, 10 input cannot be opened, 11 output cannot be opened, 20 no GPU, 21 GPU error, 22 write error,
 // 23 the input is not SAM (message on stderr).
 #include <errno.h>
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -45,8 +46,17 @@ int main(int argc, char** argv) {
         else in.push_back(a);
     }
     if (in.empty()) return usage();
+    const bool verbose = getenv("MKT_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sam2bam] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     mkt_bam* b = nullptr;
     int rc = mkt_bam_create(device, &b);
+    mark("GPU context");
     if (rc != MKT_OK) { fprintf(stderr, "sam2bam: %s\n", mkt_strerror(rc)); return rc == MKT_E_NO_DEVICE ? 20 : 21; }
     auto fail = [&](int code, const char* what) { fprintf(stderr, "sam2bam: %s: %s\n", what, mkt_bam_error(b)); mkt_bam_destroy(b); return code; };
     const size_t piece = (size_t)64 << 20;
@@ -61,9 +71,11 @@ int main(int argc, char** argv) {
         }
         if (f != stdin) fclose(f);
     }
+    mark("read + copy to the GPU");
     uint64_t nrec = 0, nbam = 0, nbai = 0;
     rc = mkt_bam_run(b, sorted, level, &nrec, &nbam, &nbai);
     if (rc != MKT_OK) return fail(rc == MKT_E_ARG ? 23 : 21, "mkt_bam_run");
+    mark("mkt_bam_run");
     FILE* fo = out == "-" ? stdout : fopen(out.c_str(), "wb");
     if (!fo) { fprintf(stderr, "sam2bam: cannot open %s: %s\n", out.c_str(), strerror(errno)); mkt_bam_destroy(b); return 11; }
     for (uint64_t off = 0; off < nbam; off += piece) {
@@ -84,6 +96,8 @@ int main(int argc, char** argv) {
         const bool okw = fwrite(ib.data(), 1, nbai, fi) == nbai;
         if (fclose(fi) != 0 || !okw) { fprintf(stderr, "sam2bam: write error on %s\n", ip.c_str()); mkt_bam_destroy(b); return 22; }
     }
+    mark("fetch + write");
     mkt_bam_destroy(b);
+    mark("teardown");
     return 0;
 }
