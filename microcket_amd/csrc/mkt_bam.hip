@@ -377,9 +377,10 @@ __device__ inline uint32_t crc_bytes(const uint8_t* d, uint32_t n, const uint32_
 }
 struct CrcTabs { uint32_t t[256]; uint32_t x2n[32]; };
 
-// block-wide CRC of n bytes at src (global or LDS): slices of ceil(n / BWG) bytes
-__device__ inline uint32_t block_crc(const uint8_t* src, uint32_t n, const uint32_t* tabl, const uint32_t* x2n, uint32_t* sh /* [BWG / 64] */) {
-    const uint32_t per = (n + BWG - 1) / BWG;
+// block-wide CRC of n bytes at src (global or LDS): slices of ceil(n / NTH) bytes
+template <int NTH>
+__device__ inline uint32_t block_crc(const uint8_t* src, uint32_t n, const uint32_t* tabl, const uint32_t* x2n, uint32_t* sh /* [NTH / 64] */) {
+    const uint32_t per = (n + NTH - 1) / NTH;
     const uint32_t a = threadIdx.x * per < n ? threadIdx.x * per : n, b = a + per < n ? a + per : n;
     uint32_t c = 0;
     if (b > a) { c = crc_bytes(src + a, b - a, tabl); if (n - b) c = crc_mulmod(crc_x8n(n - b, x2n), c); }
@@ -389,7 +390,7 @@ __device__ inline uint32_t block_crc(const uint8_t* src, uint32_t n, const uint3
     __syncthreads();
     uint32_t r = 0;
 #pragma unroll
-    for (int w = 0; w < BWG / 64; ++w) r ^= sh[w];
+    for (int w = 0; w < NTH / 64; ++w) r ^= sh[w];
     __syncthreads();
     return r;
 }
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(BWG) void k_bgzf_stored(const uint8_t* raw, uint64_
     const uint32_t n = (uint32_t)(nraw - b0 < BGZF_RAW ? nraw - b0 : BGZF_RAW);
     const uint8_t* src = raw + b0;
     uint8_t* o = comp + (uint64_t)blockIdx.x * BGZF_STRIDE;
-    const uint32_t crc = block_crc(src, n, tabl, x2n, sh);
+    const uint32_t crc = block_crc<BWG>(src, n, tabl, x2n, sh);
     const uint32_t total = 18 + 5 + n + 8;
     if (threadIdx.x == 0) {
         bgzf_header(o, total - 1);
@@ -430,12 +431,18 @@ __global__ __launch_bounds__(BWG) void k_bgzf_pack(const uint8_t* comp, const ui
 }
 
 // ---- level 1: LZ77 + fixed Huffman codes (RFC 1951 3.2.6), one workgroup per BGZF block --------------------------------------
-// Every wave compresses a quarter of the block with its own hash table (matches stay inside the quarter, <= 16 KiB back), 64
+// Every wave compresses its share of the block (an eighth by default) with its own hash table (matches stay inside the share), 64
 // positions per step: a hash of four bytes names a candidate from earlier steps (plus distance 1 for runs), lengths are
 // compared, the greedy parse of the step (which positions start a token) comes from pointer doubling over the wave, the bit
 // lengths are scanned and the codes ORed into the wave's stream.  The four streams are then joined bit-exactly.
-constexpr uint32_t DZ_Q = BGZF_RAW / 4;                  // 16320 bytes per wave
-constexpr uint32_t DZ_HBITS = 12;
+#ifndef MKT_DZ_WAVES
+#define MKT_DZ_WAVES 8
+#endif
+constexpr int DZ_WAVES = MKT_DZ_WAVES;                  // waves per BGZF block (4, 8 or 16); 64 KiB of hash tables in all
+constexpr int DZ_THREADS = 64 * DZ_WAVES;
+constexpr uint32_t DZ_Q = BGZF_RAW / DZ_WAVES;           // bytes per wave (BGZF_RAW = 2^8 * 255 divides evenly)
+constexpr uint32_t DZ_HBITS = DZ_WAVES == 4 ? 12 : (DZ_WAVES == 8 ? 11 : 10);
+static_assert(DZ_Q * DZ_WAVES == BGZF_RAW, "even split");
 constexpr uint32_t DZ_MAXLEN = 258, DZ_MINLEN = 4;
 constexpr uint32_t DZ_QWORDS = (DZ_Q * 9 / 8 + 64) / 4 + 2;       // worst case 9 bits per literal
 
@@ -465,29 +472,20 @@ __device__ inline void dist_code(uint32_t dist, uint32_t& sym, uint32_t& eb, uin
     ev = d & ((1u << eb) - 1u);
 }
 
-__global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64_t nraw, const CrcTabs* ct, uint8_t* comp, uint64_t* csize, uint32_t* scratch /* per block 4 * DZ_QWORDS */) {
-    __shared__ __attribute__((aligned(16))) uint32_t in32[(BGZF_RAW + 16) / 4];
-    __shared__ uint32_t htab[4][1u << DZ_HBITS];
-    __shared__ uint32_t stage_[4][80];                    // one step's bits of a wave: 64 tokens of <= 31 bits + the carry
-    __shared__ uint32_t tabl[256], x2n[32], sh[BWG / 64];
-    __shared__ uint32_t wbits[4];
+__global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw, uint64_t nraw, const CrcTabs* ct, uint8_t* comp, uint64_t* csize, uint32_t* scratch /* per block DZ_WAVES * DZ_QWORDS */) {
+    __shared__ __attribute__((aligned(16))) uint32_t in32[(BGZF_RAW + 288) / 4];      // + what a length measurement reads past the end
+    __shared__ uint32_t htab[DZ_WAVES][1u << DZ_HBITS];
+    __shared__ uint32_t stage_[DZ_WAVES][80];                    // one step's bits of a wave: 64 tokens of <= 31 bits + the carry
+    __shared__ uint32_t tabl[256], x2n[32], sh[DZ_THREADS / 64];
+    __shared__ uint32_t wbits[DZ_WAVES], woff[DZ_WAVES + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint8_t* in = reinterpret_cast<uint8_t*>(in32);
     auto word_at = [&](uint32_t off) {                   // the four bytes at any offset (two aligned reads)
         const uint32_t i = off >> 2;
         return __builtin_amdgcn_alignbyte(in32[i + 1], in32[i], off & 3u);
     };
-    auto match_len = [&](uint32_t c, uint32_t p, uint32_t lim) {
-        uint32_t l = 0;
-        while (l < lim) {
-            const uint32_t x = word_at(c + l) ^ word_at(p + l);
-            if (x) { l += (uint32_t)__builtin_ctz(x) >> 3; break; }
-            l += 4;
-        }
-        return l < lim ? l : lim;
-    };
     volatile uint32_t (*stage)[80] = stage_;             // lanes of a wave hand bits to each other through it
-    tabl[tid] = ct->t[tid];
+    if (tid < 256) tabl[tid] = ct->t[tid];
     if (tid < 32) x2n[tid] = ct->x2n[tid];
     const uint64_t b0 = (uint64_t)blockIdx.x * BGZF_RAW;
     const uint32_t n = (uint32_t)(nraw - b0 < BGZF_RAW ? nraw - b0 : BGZF_RAW);
@@ -495,14 +493,14 @@ __global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64
         // and what lies behind byte n is never looked at)
         const uint4* src = reinterpret_cast<const uint4*>(raw + b0);
         uint4* dst = reinterpret_cast<uint4*>(in32);
-        for (uint32_t i = tid; i < (BGZF_RAW + 16) / 16; i += BWG) dst[i] = (i << 4) < n ? src[i] : make_uint4(0, 0, 0, 0);
+        for (uint32_t i = tid; i < (BGZF_RAW + 288) / 16; i += DZ_THREADS) dst[i] = (i << 4) < n ? src[i] : make_uint4(0, 0, 0, 0);
     }
     for (uint32_t i = lane; i < (1u << DZ_HBITS); i += 64) htab[wv][i] = 0;          // 0 = empty (positions are stored + 1)
     __syncthreads();
-    const uint32_t crc = block_crc(in, n, tabl, x2n, sh);
+    const uint32_t crc = block_crc<DZ_THREADS>(in, n, tabl, x2n, sh);
     // ---- this wave's quarter
     const uint32_t q0 = wv * DZ_Q < n ? wv * DZ_Q : n, q1 = q0 + DZ_Q < n ? q0 + DZ_Q : n;
-    uint32_t* ws = scratch + ((uint64_t)blockIdx.x * 4 + wv) * DZ_QWORDS;
+    uint32_t* ws = scratch + ((uint64_t)blockIdx.x * DZ_WAVES + wv) * DZ_QWORDS;
     uint32_t wpos = 0;                                   // whole words already flushed to ws
     uint32_t carry_bits = 0;                             // bits waiting in stage[wv][0]
     if (wv == 0) { if (lane == 0) stage[0][0] = 3u; carry_bits = 3; }        // BFINAL = 1, BTYPE = 01 (bits: 1, then 01 LSB first = 1 | 1 << 1)
@@ -514,44 +512,56 @@ __global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64
         uint32_t mlen = 0, mdist = 0;
         uint32_t h = 0;
         const bool hashable = live && p + DZ_MINLEN <= q1;
-        const bool open_step = cur < base + 64u;          // (uniform) false: a match from an earlier step covers all 64 positions
+        const bool open_step = cur < base + 64u && cur < q1;      // (uniform) false: an earlier token covers all 64 positions
+        // every position's candidate, checked on its first four bytes only: distance 1 (runs) before the table's
+        uint32_t cand = 0xFFFFFFFFu;
         if (hashable) {
             const uint32_t v = word_at(p);
             h = (v * 2654435761u) >> (32 - DZ_HBITS);
             const uint32_t c1 = htab[wv][h];
-            const uint32_t lim = q1 - p < DZ_MAXLEN ? q1 - p : DZ_MAXLEN;
-            if (open_step && c1) {
-                const uint32_t c = c1 - 1;               // < base: only earlier steps have written
-                const uint32_t l = match_len(c, p, lim);
-                if (l >= DZ_MINLEN) { mlen = l; mdist = p - c; }
-            }
-            if (open_step && p > q0 && mlen < lim && in[p - 1] == in[p]) {       // runs: distance 1
-                const uint32_t l = match_len(p - 1, p, lim);
-                if (l >= DZ_MINLEN && l > mlen) { mlen = l; mdist = 1; }
+            if (open_step) {
+                if (p > q0 && word_at(p - 1u) == v) cand = p - 1u;
+                else if (c1 && word_at(c1 - 1u) == v) cand = c1 - 1u;          // < base: only earlier steps have written
             }
         }
         // (all lanes have read the table before any lane of this wave writes: one wave, program order)
         if (hashable) atomicMax(&htab[wv][h], p + 1);
-        // greedy parse of the step by pointer doubling: nxt = first position after this position's token
-        uint32_t nxt = live ? lane + (mlen ? mlen : 1u) : 64u;           // relative to base; >= 64: leaves the step
-        if (nxt < 64u && base + nxt >= q1) nxt = 64u;     // the quarter ends inside this step: the lanes behind it are not positions
-        uint64_t vis = 1ull << lane;                      // positions visited from here (inside the step)
-        uint32_t f = nxt;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t src = f < 64u ? f : (uint32_t)lane;
-            const uint64_t v2 = (uint64_t)__shfl((long long)vis, (int)src, 64);
-            const uint32_t f2 = (uint32_t)__shfl((int)f, (int)src, 64);
-            if (f < 64u) { vis |= v2; f = f2; }
-        }
-        const uint32_t start = cur - base;                // < 64 or the whole step is covered
+        // greedy parse of the step, token by token; literals are skipped in bulk, a match's length is measured by the whole
+        // wave at once (lane i compares bytes 4 i .. 4 i + 3), so the cost does not grow with the length
         uint64_t sel = 0;
-        uint32_t fend = start;
-        if (start < 64u && cur < q1) {                   // (cur == q1: the last token ended with the quarter)
-            sel = (uint64_t)__shfl((long long)vis, (int)start, 64);
-            fend = (uint32_t)__shfl((int)f, (int)start, 64);
+        if (open_step) {
+            const uint64_t hasm = __ballot(cand != 0xFFFFFFFFu);
+            const uint32_t nlive = q1 - base < 64u ? q1 - base : 64u;
+            uint32_t pos = cur - base;
+            while (pos < nlive) {
+                const uint64_t rem = hasm >> pos;
+                const uint32_t lit = rem ? (uint32_t)__builtin_ctzll(rem) : 64u;       // literals up to the next candidate
+                if (lit) {
+                    const uint32_t e = pos + lit < nlive ? pos + lit : nlive;
+                    sel |= (e >= 64u ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << pos) - 1ull);
+                    pos = e;
+                    continue;
+                }
+                const uint32_t c = (uint32_t)__shfl((int)cand, (int)pos, 64), pp = base + pos;
+                const uint32_t lim = q1 - pp < DZ_MAXLEN ? q1 - pp : DZ_MAXLEN;
+                const uint32_t x = word_at(c + 4u * (uint32_t)lane) ^ word_at(pp + 4u * (uint32_t)lane);
+                const uint64_t ne = __ballot(x != 0u);
+                uint32_t len;
+                if (ne) {
+                    const int j = (int)__builtin_ctzll(ne);
+                    const uint32_t xj = (uint32_t)__shfl((int)x, j, 64);
+                    len = 4u * (uint32_t)j + ((uint32_t)__builtin_ctz(xj) >> 3);
+                } else {                                         // 256 equal bytes: two more decide between 256, 257, 258
+                    const uint32_t y = word_at(c + 256u) ^ word_at(pp + 256u);
+                    len = 256u + ((y & 0xFFu) ? 0u : ((y & 0xFF00u) ? 1u : 2u));
+                }
+                if (len > lim) len = lim;
+                if ((uint32_t)lane == pos) { mlen = len; mdist = pp - c; }
+                sel |= 1ull << pos;
+                pos += len;
+            }
+            cur = base + pos;
         }
-        cur = base + fend;                                // (uniform)
         const bool mine = (sel >> lane) & 1ull;
         // token bits
         uint64_t bits = 0;
@@ -601,9 +611,10 @@ __global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64
     if (lane == 0) { ws[wpos] = stage[wv][0]; wbits[wv] = wpos * 32u + carry_bits; }
     __threadfence_block();
     __syncthreads();
-    // ---- join: stream 0 .. 3, then the end-of-block code (7 zero bits)
-    const uint32_t nb0 = wbits[0], nb1 = wbits[1], nb2 = wbits[2], nb3 = wbits[3];
-    const uint32_t o1 = nb0, o2 = o1 + nb1, o3 = o2 + nb2, oe = o3 + nb3, total_bits = oe + 7u;
+    // ---- join: the waves' streams in order, then the end-of-block code (7 zero bits)
+    if (tid == 0) { uint32_t a = 0; for (int w = 0; w < DZ_WAVES; ++w) { woff[w] = a; a += wbits[w]; } woff[DZ_WAVES] = a; }
+    __syncthreads();
+    const uint32_t total_bits = woff[DZ_WAVES] + 7u;
     const uint32_t cbytes = (total_bits + 7u) >> 3;
     uint8_t* o = comp + (uint64_t)blockIdx.x * BGZF_STRIDE;
     if (cbytes >= n + 5u) {                               // did not shrink: stored
@@ -615,18 +626,17 @@ __global__ __launch_bounds__(BWG) void k_bgzf_deflate(const uint8_t* raw, uint64
             put32(e, crc); put32(e, n);
             csize[blockIdx.x] = total;
         }
-        for (uint32_t i = tid; i < n; i += BWG) o[23 + i] = in[i];
+        for (uint32_t i = tid; i < n; i += DZ_THREADS) o[23 + i] = in[i];
         return;
     }
-    const uint32_t* s0 = scratch + ((uint64_t)blockIdx.x * 4) * DZ_QWORDS;
+    const uint32_t* s0 = scratch + ((uint64_t)blockIdx.x * DZ_WAVES) * DZ_QWORDS;
     // output word k holds bits [32 k, 32 k + 32) of the joined stream: each comes from one or two streams
     const uint32_t nwords = (total_bits + 31u) >> 5;
-    for (uint32_t k = tid; k < nwords; k += BWG) {
+    for (uint32_t k = tid; k < nwords; k += DZ_THREADS) {
         uint32_t word = 0;
         const uint32_t lo = k << 5, hi = lo + 32u;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint32_t so = s == 0 ? 0u : (s == 1 ? o1 : (s == 2 ? o2 : o3)), sn = s == 0 ? nb0 : (s == 1 ? nb1 : (s == 2 ? nb2 : nb3));
+        for (int s = 0; s < DZ_WAVES; ++s) {
+            const uint32_t so = woff[s], sn = wbits[s];
             if (sn == 0u || so >= hi || so + sn <= lo) continue;
             const uint32_t* sw = s0 + (uint64_t)s * DZ_QWORDS;
             // bits of stream s that land in this word: stream bit j -> joined bit so + j
@@ -1058,8 +1068,8 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
     BALLOC(d_comp, nblocks * (uint64_t)BGZF_STRIDE + 64);
     BALLOC(d_csize, (nblocks + 2) * sizeof(uint64_t));
     if (level > 0) {
-        BALLOC(d_scratch, nblocks * 4ull * DZ_QWORDS * sizeof(uint32_t) + 64);
-        hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nblocks), dim3(BWG), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize, d_scratch);
+        BALLOC(d_scratch, nblocks * (uint64_t)DZ_WAVES * DZ_QWORDS * sizeof(uint32_t) + 64);
+        hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nblocks), dim3(DZ_THREADS), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize, d_scratch);
     } else {
         hipLaunchKernelGGL(k_bgzf_stored, dim3((unsigned)nblocks), dim3(BWG), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize);
     }

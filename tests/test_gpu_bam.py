@@ -151,6 +151,39 @@ def test_synthetic_sam_round_trip(profile, groups, level):
         assert bam.compressed < 0.8 * bam.raw_len          # (fixed Huffman codes + matches: the synthetic text has long runs of F)
 
 
+def test_deflate_on_repetitive_and_random_data():
+    """match lengths around 255..258, distances 1, 2, 300 and none at all; every block must inflate to the stored block's bytes"""
+    import microcket_amd as m
+    rng = random.Random(3)
+    rnd = lambda k: "".join(rng.choice("ACGTNacgtn0123456789:;<=>?@") for _ in range(k))
+    lines = []
+    blk = rnd(300)
+    for i, z in enumerate(["A" * 1000, "AB" * 600, blk * 4, rnd(2000), "Q" * 255, "Q" * 256 + "x", "R" * 257 + "y", "S" * 258 + "z", "T" * 259, "U" * 262 + "ab" * 131, rnd(7) * 200]):
+        for rep in range(40):
+            q = "".join(chr(33 + rng.randrange(0, 41)) for _ in range(50))
+            sq = "".join(rng.choice("ACGT") for _ in range(50))
+            lines.append(f"read{i}_{rep}\t0\tchr1\t{1 + rng.randrange(10 ** 6)}\t60\t50M\t*\t0\t0\t{sq}\t{q}\tXZ:Z:{z}\tXr:Z:{rnd(rng.randrange(0, 40))}")
+    body = ("\n".join(lines) + "\n").encode()
+    hdr = b"@SQ\tSN:chr1\tLN:250000000\n"
+    for sorted_ in (False, True):
+        b0, _, n0 = m.sam_to_bam(hdr + body, sorted=sorted_, level=0)
+        b1, i1, n1 = m.sam_to_bam(hdr + body, sorted=sorted_, level=1)
+        raw0 = b"".join(r for _, _, r in bamio.bgzf_blocks(b0))
+        raw1 = b"".join(r for _, _, r in bamio.bgzf_blocks(b1))
+        assert raw0 == raw1 and n0 == n1 == len(lines)
+        assert len(b1) < 0.5 * len(b0)
+    check_bam(hdr + b"@PG\tID:bwa\tPN:bwa\tVN:0.7.17\tCL:bwa mem -5 -S -P\n", body, *m.sam_to_bam(hdr + b"@PG\tID:bwa\tPN:bwa\tVN:0.7.17\tCL:bwa mem -5 -S -P\n" + body), True, ["chr1"])
+
+
+def test_many_blocks_and_chunked_input():
+    import microcket_amd as m
+    body = util.synth("unc", 23, 40000)
+    hdr, order = header_for(body)
+    bam_b, bai_b, n = m.sam_to_bam(hdr + body, sorted=True, level=1, piece=(1 << 20) + 12345)
+    bam = check_bam(hdr, body, bam_b, bai_b, n, True, order)
+    assert bam.nblocks > 300
+
+
 def test_errors_are_reported():
     import microcket_amd as m
     hdr = b"@SQ\tSN:chr1\tLN:1000\n"
