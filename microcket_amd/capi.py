@@ -489,7 +489,7 @@ def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes"
     return p.returncode, p.stdout, p.stderr
 
 
-def sam_to_bam(sam: bytes, sorted=True, level=1, device=0, piece=1 << 24):
+def sam_to_bam(sam: bytes, sorted=True, level=2, device=0, piece=1 << 24):
     """SAM text (header lines + alignment lines) -> (BAM bytes, BAI bytes or b"", records) on the GPU: mkt_bam_* in include/mkt.h."""
     L = load_library()
     h = C.c_void_p()

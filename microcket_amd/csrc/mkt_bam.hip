@@ -430,11 +430,16 @@ __global__ __launch_bounds__(BWG) void k_bgzf_pack(const uint8_t* comp, const ui
     for (uint32_t i = threadIdx.x; i < n; i += BWG) out[o + i] = s[i];
 }
 
-// ---- level 1: LZ77 + fixed Huffman codes (RFC 1951 3.2.6), one workgroup per BGZF block --------------------------------------
-// Every wave compresses its share of the block (an eighth by default) with its own hash table (matches stay inside the share), 64
-// positions per step: a hash of four bytes names a candidate from earlier steps (plus distance 1 for runs), lengths are
-// compared, the greedy parse of the step (which positions start a token) comes from pointer doubling over the wave, the bit
-// lengths are scanned and the codes ORed into the wave's stream.  The four streams are then joined bit-exactly.
+// ---- levels 1 and 2: LZ77 + Huffman codes (RFC 1951), one workgroup per BGZF block ------------------------------------------
+// Every wave parses its share of the block (an eighth by default) with its own hash table (matches stay inside the share), 64
+// positions per step: a hash of four bytes names a candidate from earlier steps (distance 1 first, for runs), checked on four
+// bytes in parallel; then the greedy parse of the step token by token -- literals skipped in bulk, a match's length measured
+// by the whole wave at once -- and the tokens go to a list.  Level 1 codes them with the fixed tables of RFC 1951 3.2.6, level 2
+// with tables built for the block (3.2.7): symbol counts gathered while parsing, code lengths by the in-place minimum-redundancy
+// algorithm of Moffat and Katajainen on the sorted counts, limited to 15 (7) bits by moving codes down the Kraft sum, canonical
+// codes, the code lengths themselves run-length coded as the format prescribes.  Second pass: 64 tokens per step to bits, bit
+// offsets by a wave scan, ORed into the wave's stream; header, the waves' streams and the end-of-block code are then joined
+// bit-exactly.  A block that does not shrink is stored.
 #ifndef MKT_DZ_WAVES
 #define MKT_DZ_WAVES 8
 #endif
@@ -444,16 +449,12 @@ constexpr uint32_t DZ_Q = BGZF_RAW / DZ_WAVES;           // bytes per wave (BGZF
 constexpr uint32_t DZ_HBITS = DZ_WAVES == 4 ? 12 : (DZ_WAVES == 8 ? 11 : 10);
 static_assert(DZ_Q * DZ_WAVES == BGZF_RAW, "even split");
 constexpr uint32_t DZ_MAXLEN = 258, DZ_MINLEN = 4;
-constexpr uint32_t DZ_QWORDS = (DZ_Q * 9 / 8 + 64) / 4 + 2;       // worst case 9 bits per literal
+constexpr uint32_t DZ_QWORDS = (DZ_Q * 15 / 8 + 64) / 4 + 2;      // a wave's bit stream: at most 15 bits per byte
+constexpr uint32_t DZ_WAVE_SCRATCH = DZ_Q + DZ_QWORDS;            // words per wave: token list + bit stream
+constexpr int DZ_STAGE = 104;                            // one step's bits of a wave: 64 tokens of <= 48 bits + the carry
+constexpr int DZ_HDRW = 176;                             // dynamic block header: <= 3 + 14 + 57 + 316 * 14 bits
 
 __device__ inline uint32_t bitrev(uint32_t v, int n) { return __brev(v) >> (32 - n); }
-// fixed Huffman code of a literal / length symbol, already reversed for LSB-first packing
-__device__ inline void fix_litlen(uint32_t sym, uint32_t& code, uint32_t& nb) {
-    if (sym < 144) { code = bitrev(0x30 + sym, 8); nb = 8; }
-    else if (sym < 256) { code = bitrev(0x190 + (sym - 144), 9); nb = 9; }
-    else if (sym < 280) { code = bitrev(sym - 256, 7); nb = 7; }
-    else { code = bitrev(0xC0 + (sym - 280), 8); nb = 8; }
-}
 __device__ inline void len_code(uint32_t len, uint32_t& sym, uint32_t& eb, uint32_t& ev) {       // 3..258
     if (len == 258) { sym = 285; eb = 0; ev = 0; return; }
     const uint32_t l = len - 3;
@@ -471,23 +472,92 @@ __device__ inline void dist_code(uint32_t dist, uint32_t& sym, uint32_t& eb, uin
     sym = 2 * k + ((d >> eb) & 1u);
     ev = d & ((1u << eb) - 1u);
 }
+// code lengths for n symbols whose counts stand in A[0, n) in ascending order (Moffat & Katajainen, "In-place calculation of
+// minimum-redundancy codes", 1995): A[i] becomes the length of the i-th rarest symbol's code.  One lane.
+__device__ inline void mk_lengths(uint32_t* A, int n) {
+    if (n == 0) return;
+    if (n == 1) { A[0] = 1; return; }
+    A[0] += A[1];
+    int root = 0, leaf = 2, next;
+    for (next = 1; next < n - 1; ++next) {
+        if (leaf >= n || A[root] < A[leaf]) { A[next] = A[root]; A[root++] = (uint32_t)next; } else A[next] = A[leaf++];
+        if (leaf >= n || (root < next && A[root] < A[leaf])) { A[next] += A[root]; A[root++] = (uint32_t)next; } else A[next] += A[leaf++];
+    }
+    A[n - 2] = 0;
+    for (next = n - 3; next >= 0; --next) A[next] = A[A[next]] + 1;
+    int avbl = 1, used = 0, dpth = 0;
+    root = n - 2; next = n - 1;
+    while (avbl > 0) {
+        while (root >= 0 && (int)A[root] == dpth) { ++used; --root; }
+        while (avbl > used) { A[next--] = (uint32_t)dpth; --avbl; }
+        avbl = 2 * used; ++dpth; used = 0;
+    }
+}
+// One lane: lengths (<= maxbits) and canonical codes for the n used symbols listed rarest first in ssym (their counts in skey);
+// table[sym] = bit-reversed code | length << 16 (0 for unused symbols).
+__device__ inline void huff_codes(uint32_t* skey, const uint16_t* ssym, int n, int maxbits, uint32_t* table, int nsym) {
+    uint32_t num[33];
+    for (int i = 0; i <= 32; ++i) num[i] = 0;
+    mk_lengths(skey, n);
+    for (int i = 0; i < n; ++i) num[skey[i] > 32u ? 32u : skey[i]]++;
+    for (int i = maxbits + 1; i <= 32; ++i) { num[maxbits] += num[i]; num[i] = 0; }
+    uint32_t total = 0;
+    for (int i = maxbits; i > 0; --i) total += num[i] << (maxbits - i);
+    while (total > (1u << maxbits)) {                    // too many long codes: one leaves the deepest level, one code one level up splits
+        num[maxbits]--;
+        for (int i = maxbits - 1; i > 0; --i) if (num[i]) { num[i]--; num[i + 1] += 2; break; }
+        --total;
+    }
+    for (int s = 0; s < nsym; ++s) table[s] = 0;
+    int j = n;
+    for (int i = 1; i <= maxbits; ++i) for (uint32_t l = num[i]; l > 0; --l) table[ssym[--j]] = (uint32_t)i << 16;      // short codes to the frequent
+    uint32_t next_code[17];
+    uint32_t code = 0;
+    next_code[0] = 0;
+    for (int i = 1; i <= maxbits; ++i) { code = (code + num[i - 1]) << 1; next_code[i] = code; }
+    for (int s = 0; s < nsym; ++s) {
+        const uint32_t l = table[s] >> 16;
+        if (l) table[s] |= bitrev(next_code[l]++, (int)l);
+    }
+}
+struct BitSink {                                         // one lane appends bits to words in LDS
+    uint32_t* w; uint32_t n;
+    __device__ inline void put(uint32_t v, uint32_t nb) {
+        if (!nb) return;
+        const uint32_t i = n >> 5, s = n & 31u;
+        w[i] |= v << s;
+        if (s + nb > 32u) w[i + 1] |= v >> (32u - s);
+        n += nb;
+    }
+};
 
-__global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw, uint64_t nraw, const CrcTabs* ct, uint8_t* comp, uint64_t* csize, uint32_t* scratch /* per block DZ_WAVES * DZ_QWORDS */) {
+template <bool DYN>
+__global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw, uint64_t nraw, uint64_t first_block, const CrcTabs* ct, uint8_t* comp, uint64_t* csize,
+                                                             uint32_t* scratch /* per block of the launch: DZ_WAVES * DZ_WAVE_SCRATCH words */) {
     __shared__ __attribute__((aligned(16))) uint32_t in32[(BGZF_RAW + 288) / 4];      // + what a length measurement reads past the end
     __shared__ uint32_t htab[DZ_WAVES][1u << DZ_HBITS];
-    __shared__ uint32_t stage_[DZ_WAVES][80];                    // one step's bits of a wave: 64 tokens of <= 31 bits + the carry
+    __shared__ uint32_t stage_[DZ_WAVES][DZ_STAGE];
     __shared__ uint32_t tabl[256], x2n[32], sh[DZ_THREADS / 64];
-    __shared__ uint32_t wbits[DZ_WAVES], woff[DZ_WAVES + 1];
+    __shared__ uint32_t wbits[DZ_WAVES + 2], woff[DZ_WAVES + 3], wntok[DZ_WAVES];
+    __shared__ uint32_t ll_tab[288], d_tab[32];          // symbol -> reversed code | length << 16
+    __shared__ uint32_t ll_hist[288], d_hist[32];
+    __shared__ uint32_t skey[288], dkey[32];
+    __shared__ uint16_t ssym[288], dsym[32];
+    __shared__ uint32_t hdrw[DZ_HDRW];
+    __shared__ uint32_t nused[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint8_t* in = reinterpret_cast<uint8_t*>(in32);
     auto word_at = [&](uint32_t off) {                   // the four bytes at any offset (two aligned reads)
         const uint32_t i = off >> 2;
         return __builtin_amdgcn_alignbyte(in32[i + 1], in32[i], off & 3u);
     };
-    volatile uint32_t (*stage)[80] = stage_;             // lanes of a wave hand bits to each other through it
+    volatile uint32_t (*stage)[DZ_STAGE] = stage_;       // lanes of a wave hand bits to each other through it
     if (tid < 256) tabl[tid] = ct->t[tid];
-    if (tid < 32) x2n[tid] = ct->x2n[tid];
-    const uint64_t b0 = (uint64_t)blockIdx.x * BGZF_RAW;
+    if (tid < 32) { x2n[tid] = ct->x2n[tid]; d_hist[tid] = 0; }
+    if (tid < 288) ll_hist[tid] = 0;
+    for (int i = tid; i < DZ_HDRW; i += DZ_THREADS) hdrw[i] = 0;
+    const uint64_t blk = first_block + blockIdx.x;
+    const uint64_t b0 = blk * BGZF_RAW;
     const uint32_t n = (uint32_t)(nraw - b0 < BGZF_RAW ? nraw - b0 : BGZF_RAW);
     {   // the block into LDS, 16 bytes per load (blocks start on multiples of 16; the raw buffer is readable 64 bytes past its end,
         // and what lies behind byte n is never looked at)
@@ -498,13 +568,11 @@ __global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw,
     for (uint32_t i = lane; i < (1u << DZ_HBITS); i += 64) htab[wv][i] = 0;          // 0 = empty (positions are stored + 1)
     __syncthreads();
     const uint32_t crc = block_crc<DZ_THREADS>(in, n, tabl, x2n, sh);
-    // ---- this wave's quarter
+    // ---- pass 1: this wave's share -> tokens (a literal byte, or 1 << 31 | length - 3 << 16 | distance - 1)
     const uint32_t q0 = wv * DZ_Q < n ? wv * DZ_Q : n, q1 = q0 + DZ_Q < n ? q0 + DZ_Q : n;
-    uint32_t* ws = scratch + ((uint64_t)blockIdx.x * DZ_WAVES + wv) * DZ_QWORDS;
-    uint32_t wpos = 0;                                   // whole words already flushed to ws
-    uint32_t carry_bits = 0;                             // bits waiting in stage[wv][0]
-    if (wv == 0) { if (lane == 0) stage[0][0] = 3u; carry_bits = 3; }        // BFINAL = 1, BTYPE = 01 (bits: 1, then 01 LSB first = 1 | 1 << 1)
-    else if (lane == 0) stage[wv][0] = 0;
+    uint32_t* wtok = scratch + ((uint64_t)blockIdx.x * DZ_WAVES + wv) * DZ_WAVE_SCRATCH;
+    uint32_t* ws = wtok + DZ_Q;
+    uint32_t ntok = 0;
     uint32_t cur = q0;                                   // first position not yet covered by a token
     for (uint32_t base = q0; base < q1; base += 64) {
         const uint32_t p = base + lane;
@@ -526,10 +594,11 @@ __global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw,
         }
         // (all lanes have read the table before any lane of this wave writes: one wave, program order)
         if (hashable) atomicMax(&htab[wv][h], p + 1);
+        if (!open_step) continue;
         // greedy parse of the step, token by token; literals are skipped in bulk, a match's length is measured by the whole
         // wave at once (lane i compares bytes 4 i .. 4 i + 3), so the cost does not grow with the length
         uint64_t sel = 0;
-        if (open_step) {
+        {
             const uint64_t hasm = __ballot(cand != 0xFFFFFFFFu);
             const uint32_t nlive = q1 - base < 64u ? q1 - base : 64u;
             uint32_t pos = cur - base;
@@ -562,39 +631,159 @@ __global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw,
             }
             cur = base + pos;
         }
-        const bool mine = (sel >> lane) & 1ull;
-        // token bits
-        uint64_t bits = 0;
-        uint32_t nb = 0;
-        if (mine) {
-            if (mlen) {
-                uint32_t sym, eb, ev, code, cb;
-                len_code(mlen, sym, eb, ev);
-                fix_litlen(sym, code, cb);
-                bits = code; nb = cb;
-                bits |= (uint64_t)ev << nb; nb += eb;
-                uint32_t ds, deb, dev;
-                dist_code(mdist, ds, deb, dev);
-                bits |= (uint64_t)bitrev(ds, 5) << nb; nb += 5;
-                bits |= (uint64_t)dev << nb; nb += deb;
-            } else {
-                uint32_t code, cb;
-                fix_litlen(in[p], code, cb);
-                bits = code; nb = cb;
+        if ((sel >> lane) & 1ull) {
+            const uint32_t rank = (uint32_t)__popcll(sel & ((1ull << lane) - 1ull));
+            wtok[ntok + rank] = mlen ? (0x80000000u | ((mlen - 3u) << 16) | (mdist - 1u)) : (uint32_t)in[p];
+            if (DYN) {
+                if (mlen) {
+                    uint32_t sy, eb, ev;
+                    len_code(mlen, sy, eb, ev);
+                    atomicAdd(&ll_hist[sy], 1u);
+                    dist_code(mdist, sy, eb, ev);
+                    atomicAdd(&d_hist[sy], 1u);
+                } else atomicAdd(&ll_hist[in[p]], 1u);
             }
         }
-        // bit offsets inside the step
+        ntok += (uint32_t)__popcll(sel);
+    }
+    if (lane == 0) wntok[wv] = ntok;
+    __syncthreads();
+    // ---- the code tables and the block header
+    uint32_t hdr_bits = 3;
+    if (!DYN) {
+        for (int s = tid; s < 288; s += DZ_THREADS) {        // RFC 1951 3.2.6
+            uint32_t code, nb;
+            if (s < 144) { code = bitrev(0x30 + s, 8); nb = 8; }
+            else if (s < 256) { code = bitrev(0x190 + (s - 144), 9); nb = 9; }
+            else if (s < 280) { code = bitrev(s - 256, 7); nb = 7; }
+            else { code = bitrev(0xC0 + (s - 280), 8); nb = 8; }
+            ll_tab[s] = code | (nb << 16);
+        }
+        if (tid < 32) d_tab[tid] = bitrev((uint32_t)tid, 5) | (5u << 16);
+        if (tid == 0) hdrw[0] = 3u;                          // BFINAL = 1, BTYPE = 01
+        __syncthreads();
+    } else {
+        if (tid == 0) {
+            ll_hist[256] = 1;                                // end of block
+            int nz = 0;
+            for (int s = 0; s < 30; ++s) nz += d_hist[s] != 0u;
+            if (nz == 0) { d_hist[0] = 1; d_hist[1] = 1; }       // (as zlib: never fewer than two distance codes)
+            else if (nz == 1) { if (d_hist[0]) d_hist[1] = 1; else d_hist[0] = 1; }
+            int nl = 0;
+            for (int s = 0; s < 286; ++s) nl += ll_hist[s] != 0u;
+            if (nl < 2) { if (!ll_hist[0]) ll_hist[0] = 1; else ll_hist[1] = 1; }
+        }
+        __syncthreads();
+        // used symbols in ascending order of their counts (rank by counting; ties by symbol)
+        for (int t = tid; t < 286; t += DZ_THREADS) {
+            const uint32_t f = ll_hist[t];
+            if (f) {
+                uint32_t r = 0;
+                for (int j = 0; j < 286; ++j) { const uint32_t g = ll_hist[j]; r += (g != 0u) && (g < f || (g == f && j < t)); }
+                skey[r] = f; ssym[r] = (uint16_t)t;
+            }
+        }
+        for (int t = DZ_THREADS - 1 - tid; t < 30; t += DZ_THREADS) {           // (the last threads: they have no literal symbol to rank)
+            const uint32_t f = d_hist[t];
+            if (f) {
+                uint32_t r = 0;
+                for (int j = 0; j < 30; ++j) { const uint32_t g = d_hist[j]; r += (g != 0u) && (g < f || (g == f && j < t)); }
+                dkey[r] = f; dsym[r] = (uint16_t)t;
+            }
+        }
+        if (tid == 0) { int a = 0; for (int s = 0; s < 286; ++s) a += ll_hist[s] != 0u; nused[0] = (uint32_t)a; }
+        if (tid == 64) { int a = 0; for (int s = 0; s < 30; ++s) a += d_hist[s] != 0u; nused[1] = (uint32_t)a; }
+        __syncthreads();
+        if (tid == 0) huff_codes(skey, ssym, (int)nused[0], 15, ll_tab, 288);
+        if (tid == 64) huff_codes(dkey, dsym, (int)nused[1], 15, d_tab, 32);
+        __syncthreads();
+        if (tid == 0) {                                      // RFC 1951 3.2.7
+            int nll = 286, nd = 30;
+            while (nll > 257 && !(ll_tab[nll - 1] >> 16)) --nll;
+            while (nd > 1 && !(d_tab[nd - 1] >> 16)) --nd;
+            // the code lengths, run-length coded: symbols 0..15 literal lengths, 16 repeat previous 3..6, 17 zeros 3..10, 18 zeros 11..138
+            uint16_t* cl = reinterpret_cast<uint16_t*>(skey);         // (the sort arrays are free again) symbol | extra value << 8
+            int ncl = 0;
+            uint32_t clh[19];
+            for (int i = 0; i < 19; ++i) clh[i] = 0;
+            const int tot = nll + nd;
+            auto L = [&](int i) { return i < nll ? ll_tab[i] >> 16 : d_tab[i - nll] >> 16; };
+            for (int i = 0; i < tot;) {
+                const uint32_t v = L(i);
+                int run = 1;
+                while (i + run < tot && L(i + run) == v) ++run;
+                i += run;
+                if (v == 0) {
+                    while (run >= 11) { const int r = run < 138 ? run : 138; cl[ncl++] = (uint16_t)(18 | ((r - 11) << 8)); clh[18]++; run -= r; }
+                    if (run >= 3) { cl[ncl++] = (uint16_t)(17 | ((run - 3) << 8)); clh[17]++; run = 0; }
+                    while (run-- > 0) { cl[ncl++] = 0; clh[0]++; }
+                } else {
+                    cl[ncl++] = (uint16_t)v; clh[v]++; --run;
+                    while (run >= 3) { const int r = run < 6 ? run : 6; cl[ncl++] = (uint16_t)(16 | ((r - 3) << 8)); clh[16]++; run -= r; }
+                    while (run-- > 0) { cl[ncl++] = (uint16_t)v; clh[v]++; }
+                }
+            }
+            // the code for those 19 symbols (<= 7 bits; never fewer than two of them)
+            { int nzc = 0, only = 0; for (int s2 = 0; s2 < 19; ++s2) if (clh[s2]) { ++nzc; only = s2; } if (nzc == 1) clh[only ? 0 : 1] = 1; }
+            uint32_t ck[19], ctab[19];
+            uint16_t cs[19];
+            int nc = 0;
+            for (int s = 0; s < 19; ++s) if (clh[s]) { int k = nc++; while (k > 0 && (ck[k - 1] > clh[s])) { ck[k] = ck[k - 1]; cs[k] = cs[k - 1]; --k; } ck[k] = clh[s]; cs[k] = (uint16_t)s; }
+            huff_codes(ck, cs, nc, 7, ctab, 19);
+            const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            int nclc = 19;
+            while (nclc > 4 && !(ctab[order[nclc - 1]] >> 16)) --nclc;
+            BitSink B{hdrw, 0};
+            B.put(5u, 3);                                    // BFINAL = 1, BTYPE = 10
+            B.put((uint32_t)(nll - 257), 5); B.put((uint32_t)(nd - 1), 5); B.put((uint32_t)(nclc - 4), 4);
+            for (int i = 0; i < nclc; ++i) B.put(ctab[order[i]] >> 16, 3);
+            for (int i = 0; i < ncl; ++i) {
+                const uint32_t sy = cl[i] & 0xFFu, ev = cl[i] >> 8;
+                B.put(ctab[sy] & 0xFFFFu, ctab[sy] >> 16);
+                if (sy == 16) B.put(ev, 2); else if (sy == 17) B.put(ev, 3); else if (sy == 18) B.put(ev, 7);
+            }
+            nused[0] = B.n;
+        }
+        __syncthreads();
+        hdr_bits = nused[0];
+    }
+    // ---- pass 2: tokens -> bits
+    ntok = wntok[wv];
+    uint32_t wpos = 0;                                   // whole words already flushed to ws
+    uint32_t carry_bits = 0;                             // bits waiting in stage[wv][0]
+    if (lane == 0) stage[wv][0] = 0;
+    for (uint32_t t0 = 0; t0 < ntok; t0 += 64) {
+        uint32_t a = 0, na = 0, b = 0, nbb = 0;          // literal / length part, distance part
+        if (t0 + lane < ntok) {
+            const uint32_t tok = wtok[t0 + lane];
+            if (tok >> 31) {
+                uint32_t sy, eb, ev;
+                len_code(((tok >> 16) & 0xFFu) + 3u, sy, eb, ev);
+                const uint32_t e = ll_tab[sy];
+                a = (e & 0xFFFFu) | (ev << (e >> 16)); na = (e >> 16) + eb;
+                dist_code((tok & 0xFFFFu) + 1u, sy, eb, ev);
+                const uint32_t d = d_tab[sy];
+                b = (d & 0xFFFFu) | (ev << (d >> 16)); nbb = (d >> 16) + eb;
+            } else { const uint32_t e = ll_tab[tok]; a = e & 0xFFFFu; na = e >> 16; }
+        }
+        const uint32_t nb = na + nbb;
         uint32_t inc = nb;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += y; }
         const uint32_t tot = (uint32_t)__shfl((int)inc, 63, 64);
         const uint32_t bo = carry_bits + inc - nb;
         // stage[1..] cleared for this step (word 0 holds the carry)
-        for (uint32_t i = 1 + lane; i < 80; i += 64) stage[wv][i] = 0;
+        for (uint32_t i = 1 + lane; i < (uint32_t)DZ_STAGE; i += 64) stage[wv][i] = 0;
         __builtin_amdgcn_wave_barrier();
-        if (nb) {
+        if (na) {
             const uint32_t w = bo >> 5, s = bo & 31u;
-            const uint64_t lo = bits << s;
+            const uint64_t lo = (uint64_t)a << s;
+            atomicOr(&stage_[wv][w], (uint32_t)lo);
+            if ((uint32_t)(lo >> 32)) atomicOr(&stage_[wv][w + 1], (uint32_t)(lo >> 32));
+        }
+        if (nbb) {
+            const uint32_t w = (bo + na) >> 5, s = (bo + na) & 31u;
+            const uint64_t lo = (uint64_t)b << s;
             atomicOr(&stage_[wv][w], (uint32_t)lo);
             if ((uint32_t)(lo >> 32)) atomicOr(&stage_[wv][w + 1], (uint32_t)(lo >> 32));
         }
@@ -608,15 +797,16 @@ __global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw,
         if (lane == 0) stage[wv][0] = carry_bits ? rest : 0u;
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) { ws[wpos] = stage[wv][0]; wbits[wv] = wpos * 32u + carry_bits; }
+    if (lane == 0) { ws[wpos] = stage[wv][0]; wbits[1 + wv] = wpos * 32u + carry_bits; }
+    if (tid == 0) { wbits[0] = hdr_bits; wbits[DZ_WAVES + 1] = ll_tab[256] >> 16; }
     __threadfence_block();
     __syncthreads();
-    // ---- join: the waves' streams in order, then the end-of-block code (7 zero bits)
-    if (tid == 0) { uint32_t a = 0; for (int w = 0; w < DZ_WAVES; ++w) { woff[w] = a; a += wbits[w]; } woff[DZ_WAVES] = a; }
+    // ---- join: header, the waves' streams in order, the end-of-block code
+    if (tid == 0) { uint32_t a = 0; for (int w = 0; w < DZ_WAVES + 2; ++w) { woff[w] = a; a += wbits[w]; } woff[DZ_WAVES + 2] = a; }
     __syncthreads();
-    const uint32_t total_bits = woff[DZ_WAVES] + 7u;
+    const uint32_t total_bits = woff[DZ_WAVES + 2];
     const uint32_t cbytes = (total_bits + 7u) >> 3;
-    uint8_t* o = comp + (uint64_t)blockIdx.x * BGZF_STRIDE;
+    uint8_t* o = comp + blk * BGZF_STRIDE;
     if (cbytes >= n + 5u) {                               // did not shrink: stored
         const uint32_t total = 18 + 5 + n + 8;
         if (tid == 0) {
@@ -624,35 +814,39 @@ __global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw,
             o[18] = 1; o[19] = (uint8_t)n; o[20] = (uint8_t)(n >> 8); o[21] = (uint8_t)~n; o[22] = (uint8_t)(~n >> 8);
             uint8_t* e = o + 23 + n;
             put32(e, crc); put32(e, n);
-            csize[blockIdx.x] = total;
+            csize[blk] = total;
         }
         for (uint32_t i = tid; i < n; i += DZ_THREADS) o[23 + i] = in[i];
         return;
     }
-    const uint32_t* s0 = scratch + ((uint64_t)blockIdx.x * DZ_WAVES) * DZ_QWORDS;
-    // output word k holds bits [32 k, 32 k + 32) of the joined stream: each comes from one or two streams
+    const uint32_t eobw = ll_tab[256] & 0xFFFFu;
+    const uint32_t* s0 = scratch + ((uint64_t)blockIdx.x * DZ_WAVES) * DZ_WAVE_SCRATCH + DZ_Q;
+    // output word k holds bits [32 k, 32 k + 32) of the joined stream
     const uint32_t nwords = (total_bits + 31u) >> 5;
     for (uint32_t k = tid; k < nwords; k += DZ_THREADS) {
         uint32_t word = 0;
         const uint32_t lo = k << 5, hi = lo + 32u;
-        for (int s = 0; s < DZ_WAVES; ++s) {
+        for (int s = 0; s < DZ_WAVES + 2; ++s) {
             const uint32_t so = woff[s], sn = wbits[s];
             if (sn == 0u || so >= hi || so + sn <= lo) continue;
-            const uint32_t* sw = s0 + (uint64_t)s * DZ_QWORDS;
+            auto sword = [&](uint32_t w) -> uint32_t {
+                if (s == 0) return hdrw[w];
+                if (s == DZ_WAVES + 1) return w ? 0u : eobw;
+                return s0[(uint64_t)(s - 1) * DZ_WAVE_SCRATCH + w];
+            };
             // bits of stream s that land in this word: stream bit j -> joined bit so + j
             const int64_t j0 = (int64_t)lo - (int64_t)so;            // stream bit at the word's bit 0 (may be negative)
             uint32_t v;
             if (j0 >= 0) {
                 const uint32_t w = (uint32_t)j0 >> 5, sft = (uint32_t)j0 & 31u;
-                const uint64_t two = (uint64_t)sw[w] | ((uint64_t)(((w + 1u) << 5) < sn ? sw[w + 1] : 0u) << 32);
+                const uint64_t two = (uint64_t)sword(w) | ((uint64_t)(((w + 1u) << 5) < sn ? sword(w + 1) : 0u) << 32);
                 v = (uint32_t)(two >> sft);
                 const uint32_t avail = sn - (uint32_t)j0;             // stream bits from j0 on
                 if (avail < 32u) v &= (1u << avail) - 1u;
             } else {
                 const uint32_t sft = (uint32_t)(-j0);                 // 1..31
-                v = sw[0] << sft;
-                const uint32_t avail = sn;                            // lands at [sft, sft + sn)
-                if (avail + sft < 32u) v &= (1u << (avail + sft)) - 1u;
+                v = sword(0) << sft;
+                if (sn + sft < 32u) v &= (1u << (sn + sft)) - 1u;
             }
             word |= v;
         }
@@ -668,7 +862,7 @@ __global__ __launch_bounds__(DZ_THREADS) void k_bgzf_deflate(const uint8_t* raw,
         bgzf_header(o, total - 1);
         uint8_t* e = o + 18 + cbytes;
         put32(e, crc); put32(e, n);
-        csize[blockIdx.x] = total;
+        csize[blk] = total;
     }
 }
 
@@ -1068,8 +1262,17 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
     BALLOC(d_comp, nblocks * (uint64_t)BGZF_STRIDE + 64);
     BALLOC(d_csize, (nblocks + 2) * sizeof(uint64_t));
     if (level > 0) {
-        BALLOC(d_scratch, nblocks * (uint64_t)DZ_WAVES * DZ_QWORDS * sizeof(uint32_t) + 64);
-        hipLaunchKernelGGL(k_bgzf_deflate, dim3((unsigned)nblocks), dim3(DZ_THREADS), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize, d_scratch);
+        // the token lists and bit streams of the blocks of one launch: at most 8 GB of scratch
+        const uint64_t per_block = (uint64_t)DZ_WAVES * DZ_WAVE_SCRATCH * sizeof(uint32_t);
+        uint64_t batch = ((uint64_t)8 << 30) / per_block;
+        if (batch > nblocks) batch = nblocks;
+        if (batch < 1) batch = 1;
+        BALLOC(d_scratch, batch * per_block + 64);
+        for (uint64_t fb = 0; fb < nblocks; fb += batch) {
+            const unsigned g = (unsigned)(nblocks - fb < batch ? nblocks - fb : batch);
+            if (level >= 2) hipLaunchKernelGGL(k_bgzf_deflate<true>, dim3(g), dim3(DZ_THREADS), 0, st, (const uint8_t*)d_raw, nraw, fb, (const CrcTabs*)d_ct, d_comp, d_csize, d_scratch);
+            else hipLaunchKernelGGL(k_bgzf_deflate<false>, dim3(g), dim3(DZ_THREADS), 0, st, (const uint8_t*)d_raw, nraw, fb, (const CrcTabs*)d_ct, d_comp, d_csize, d_scratch);
+        }
     } else {
         hipLaunchKernelGGL(k_bgzf_stored, dim3((unsigned)nblocks), dim3(BWG), 0, st, (const uint8_t*)d_raw, nraw, (const CrcTabs*)d_ct, d_comp, d_csize);
     }

@@ -8,7 +8,7 @@
 // The inputs are read one after the other as ONE SAM stream ("-" = stdin): its leading '@' lines are the header.  The work is
 // mkt_bam_* of libmkt_hip.so (include/mkt.h); this file only moves bytes.
 //   -o FILE   output BAM ("-" = stdout; then no index is written)        -u        keep the input order (samtools view -b): no sort, no index
-//   -l N      0 = stored blocks, 1 = deflate on the GPU (default)         -@ N      accepted and ignored (thread count of the tools it replaces)
+//   -l N      0 = stored blocks, 1 = fixed Huffman codes, 2 = per-block codes (default)         -@ N      accepted and ignored (thread count of the tools it replaces)
 //   --no-index                                                            -d N      GPU ordinal (default $MKT_DEVICE or 0)
 // Exit codes: 0 ok, 2 usage, 10 input cannot be opened, 11 output cannot be opened, 20 no GPU, 21 GPU error, 22 write error,
 // 23 the input is not SAM (message on stderr).
@@ -23,14 +23,14 @@
 #include "../../include/mkt.h"
 
 static int usage() {
-    fprintf(stderr, "usage: sam2bam [-o out.bam] [-u] [-l 0|1] [-@ threads] [--no-index] [-d device] <in.sam | -> [more.sam ...]\n");
+    fprintf(stderr, "usage: sam2bam [-o out.bam] [-u] [-l 0|1|2] [-@ threads] [--no-index] [-d device] <in.sam | -> [more.sam ...]\n");
     return 2;
 }
 
 int main(int argc, char** argv) {
     std::string out = "-";
     std::vector<std::string> in;
-    int sorted = 1, level = 1, index = 1, device = getenv("MKT_DEVICE") ? atoi(getenv("MKT_DEVICE")) : 0;
+    int sorted = 1, level = 2, index = 1, device = getenv("MKT_DEVICE") ? atoi(getenv("MKT_DEVICE")) : 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&](const char* what) -> const char* { if (i + 1 >= argc) { fprintf(stderr, "sam2bam: %s needs a value\n", what); exit(2); } return argv[++i]; };

@@ -113,7 +113,7 @@ EDGE_BODY = "\n".join([
 ]) + "\n"
 
 
-@pytest.mark.parametrize("level", [0, 1])
+@pytest.mark.parametrize("level", [0, 1, 2])
 def test_edge_records(level):
     import microcket_amd as m
     body = EDGE_BODY.encode()
@@ -131,7 +131,7 @@ def test_edge_records(level):
     check_bam(hdr, body, bam_b, bai_b, n, False, order)
 
 
-@pytest.mark.parametrize("profile,groups,level", [("unc", 3000, 0), ("unc", 3000, 1), ("flash", 2500, 1), ("stress", 2000, 1)])
+@pytest.mark.parametrize("profile,groups,level", [("unc", 3000, 0), ("unc", 3000, 1), ("unc", 3000, 2), ("flash", 2500, 2), ("stress", 2000, 2)])
 def test_synthetic_sam_round_trip(profile, groups, level):
     import microcket_amd as m
     body = util.synth(profile, 11, groups)
@@ -167,11 +167,14 @@ def test_deflate_on_repetitive_and_random_data():
     hdr = b"@SQ\tSN:chr1\tLN:250000000\n"
     for sorted_ in (False, True):
         b0, _, n0 = m.sam_to_bam(hdr + body, sorted=sorted_, level=0)
-        b1, i1, n1 = m.sam_to_bam(hdr + body, sorted=sorted_, level=1)
         raw0 = b"".join(r for _, _, r in bamio.bgzf_blocks(b0))
-        raw1 = b"".join(r for _, _, r in bamio.bgzf_blocks(b1))
-        assert raw0 == raw1 and n0 == n1 == len(lines)
-        assert len(b1) < 0.5 * len(b0)
+        sizes = []
+        for level in (1, 2):
+            b1, i1, n1 = m.sam_to_bam(hdr + body, sorted=sorted_, level=level)
+            raw1 = b"".join(r for _, _, r in bamio.bgzf_blocks(b1))
+            assert raw0 == raw1 and n0 == n1 == len(lines)
+            sizes.append(len(b1))
+        assert sizes[0] < 0.5 * len(b0) and sizes[1] < sizes[0]
     check_bam(hdr + b"@PG\tID:bwa\tPN:bwa\tVN:0.7.17\tCL:bwa mem -5 -S -P\n", body, *m.sam_to_bam(hdr + b"@PG\tID:bwa\tPN:bwa\tVN:0.7.17\tCL:bwa mem -5 -S -P\n" + body), True, ["chr1"])
 
 
@@ -179,7 +182,7 @@ def test_many_blocks_and_chunked_input():
     import microcket_amd as m
     body = util.synth("unc", 23, 40000)
     hdr, order = header_for(body)
-    bam_b, bai_b, n = m.sam_to_bam(hdr + body, sorted=True, level=1, piece=(1 << 20) + 12345)
+    bam_b, bai_b, n = m.sam_to_bam(hdr + body, sorted=True, level=2, piece=(1 << 20) + 12345)
     bam = check_bam(hdr, body, bam_b, bai_b, n, True, order)
     assert bam.nblocks > 300
 
