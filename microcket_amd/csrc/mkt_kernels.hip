@@ -770,6 +770,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         // cache line would queue up behind each other)
         if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
         if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
+#if defined(MKT_SAM_LINEWISE)
         if (P.write_sam && st.sums.sam_bytes) {
             const uint64_t gos = st.base.sam_bytes;
             if (gos + st.sums.sam_bytes <= s_out.sam_cap) {
@@ -796,6 +797,76 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 }
             }
         }
+#else
+        // The tile's .sam bytes are ONE contiguous range of the output (the emitting lines in order): copied destination first --
+        // every thread takes aligned 16-byte vectors of that range (full lanes, coalesced stores) and finds the line a vector
+        // lies in by bisection over the emitting lines' offsets; the text comes straight from global memory (L2).
+        const bool sam_copy = P.write_sam && st.sums.sam_bytes && st.base.sam_bytes + st.sums.sam_bytes <= s_out.sam_cap;      // (uniform)
+        uint32_t* eo = st.rc.f.pos;                                 // (the parse records are dead since the classifier)
+        uint32_t* es = st.rc.f.rclip;                               // (eo[E] may be pos[LCAP] = lclip[0], unused here)
+        uint32_t E = 0;
+        if (sam_copy) {
+            E = (uint32_t)(__popcll(st.m_emit[0]) + __popcll(st.m_emit[1]) + __popcll(st.m_emit[2]) + __popcll(st.m_emit[3]));
+            for (uint32_t i = first_idx + (uint32_t)tid; i < NLe; i += NT) {
+                if (!mask_bit(st.m_emit, i)) continue;
+                uint32_t k = (uint32_t)__popcll(st.m_emit[i >> 6] & ((1ull << (i & 63u)) - 1ull));
+                for (uint32_t w = 0; w < (i >> 6); ++w) k += (uint32_t)__popcll(st.m_emit[w]);
+                eo[k] = st.u.g.x_sam[i];
+                es[k] = st.goff[i];
+            }
+            if (tid == 0) eo[E] = (uint32_t)st.sums.sam_bytes;
+        }
+        if (P.write_sam) __syncthreads();                           // (kernel-uniform)
+        if (sam_copy && E) {
+            const uint32_t total = (uint32_t)st.sums.sam_bytes;
+            uint8_t* dbase = s_out.sam + st.base.sam_bytes;
+            const uint8_t* tbase = a.text + G.w0;
+            auto line_of = [&](uint32_t d) {                        // the emitting line that holds output byte d
+                uint32_t lo = 0, hi = E - 1u;
+                while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (eo[mid] <= d) lo = mid; else hi = mid - 1u; }
+                return lo;
+            };
+            const uint32_t head0 = (uint32_t)((16u - ((uintptr_t)dbase & 15u)) & 15u);
+            const uint32_t head = head0 < total ? head0 : total;
+            const uint32_t nv = (total - head) >> 4, tail0 = head + (nv << 4);
+            if ((uint32_t)tid < head) { const uint32_t k = line_of((uint32_t)tid); dbase[tid] = tbase[es[k] + (uint32_t)tid - eo[k]]; }
+            if ((uint32_t)tid < total - tail0) { const uint32_t d = tail0 + (uint32_t)tid, k = line_of(d); dbase[d] = tbase[es[k] + d - eo[k]]; }
+            for (uint32_t v = (uint32_t)tid; v < nv; v += NT) {
+                const uint32_t d = head + (v << 4);
+                const uint32_t k = line_of(d);
+                const uint32_t o = d - eo[k], left = eo[k + 1u] - d;               // bytes of line k from here on
+                const uint32_t so = es[k] + o;
+                uint4 x;
+                if (left >= 16u) __builtin_memcpy(&x, tbase + so, 16);
+                else if (k + 2u <= E && eo[k + 2u] - eo[k + 1u] >= 16u - left && (uint64_t)G.w0 + so + 16u <= (uint64_t)n) {
+                    // the vector ends in the next emitting line: `left` bytes from here, the rest from that line's start
+                    uint4 xa, xb;
+                    __builtin_memcpy(&xa, tbase + so, 16);
+                    __builtin_memcpy(&xb, tbase + es[k + 1u] - left, 16);
+                    const uint32_t* pa = reinterpret_cast<const uint32_t*>(&xa);
+                    const uint32_t* pb = reinterpret_cast<const uint32_t*>(&xb);
+                    uint32_t* px = reinterpret_cast<uint32_t*>(&x);
+#pragma unroll
+                    for (uint32_t q = 0; q < 4u; ++q) {
+                        const uint32_t m = left >= 4u * q + 4u ? 0xFFFFFFFFu : (left <= 4u * q ? 0u : (1u << (8u * (left - 4u * q))) - 1u);
+                        px[q] = (pa[q] & m) | (pb[q] & ~m);
+                    }
+                } else {                                            // three or more lines in 16 bytes, or the end of the block: byte by byte
+                    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+                    uint32_t kk = k, oo = so, lim = left;
+#pragma unroll
+                    for (uint32_t b2 = 0; b2 < 16u; ++b2) {
+                        while (lim == 0u) { ++kk; oo = es[kk]; lim = eo[kk + 1u] - eo[kk]; }
+                        const uint32_t by = (uint32_t)tbase[oo++] << (8u * (b2 & 3u));
+                        if (b2 < 4u) q0 |= by; else if (b2 < 8u) q1 |= by; else if (b2 < 12u) q2 |= by; else q3 |= by;
+                        --lim;
+                    }
+                    x = make_uint4(q0, q1, q2, q3);
+                }
+                *reinterpret_cast<uint4*>(dbase + d) = x;
+            }
+        }
+#endif
         __syncthreads();                                           // every lane is done with this tile's state
         STAMP(8);
     }
