@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=16_000_000, help="pairs of the file the CPU reference and the end-to-end executables are timed on (~20 s of reference time)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal only: run the N > 1 code path (process group, RCCL all_to_all of the key space) with whatever WORLD_SIZE is, even 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -181,10 +182,13 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     dist = None
     torch = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch  # noqa: F811
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.same_gpu:
             local = 0
         if args.backend == "nccl":
