@@ -255,7 +255,11 @@ void mkt_bam_destroy(mkt_bam* b);
 const char* mkt_bam_error(const mkt_bam* b);
 int mkt_bam_add(mkt_bam* b, const char* bytes, size_t n);                  /* the next bytes of the SAM stream (host; copied) */
 int mkt_bam_add_device(mkt_bam* b, const void* d_bytes, size_t n);         /* alignment lines already on the device */
+int mkt_bam_reserve(mkt_bam* b, size_t bytes);                             /* optional: room for that much alignment text up front */
+int mkt_bam_window(mkt_bam* b, char** buf, size_t* cap);                   /* a pinned 64 MiB host buffer for the next bytes of the stream ... */
+int mkt_bam_commit(mkt_bam* b, size_t n);                                  /* ... its first n bytes are those bytes (copied asynchronously; two buffers alternate) */
 int mkt_bam_run(mkt_bam* b, int sorted, int level, uint64_t* records, uint64_t* bam_bytes, uint64_t* bai_bytes);
+int mkt_bam_read(mkt_bam* b, int which, uint64_t off, size_t n, const char** ptr);  /* result bytes through the pinned buffers; *ptr valid until the next call but one */
 int mkt_bam_fetch(mkt_bam* b, int which /* 0: the BAM, 1: the BAI */, uint64_t off, char* out, size_t n);
 
 /* surviving QNAME groups seen so far (synchronises the context's stream); sharded runs exchange

@@ -18,6 +18,7 @@ EXPORTS = [
     "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
     "mkt_rmdup_create", "mkt_rmdup_destroy", "mkt_rmdup_error", "mkt_rmdup_add", "mkt_rmdup_run", "mkt_rmdup_fetch",
     "mkt_bam_create", "mkt_bam_destroy", "mkt_bam_error", "mkt_bam_add", "mkt_bam_add_device", "mkt_bam_run", "mkt_bam_fetch",
+    "mkt_bam_reserve", "mkt_bam_window", "mkt_bam_commit", "mkt_bam_read",
 ]
 
 
@@ -135,6 +136,10 @@ def load_library():
     L.mkt_bam_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mkt_bam_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mkt_bam_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
+    L.mkt_bam_reserve.argtypes = [C.c_void_p, C.c_size_t]
+    L.mkt_bam_window.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.mkt_bam_commit.argtypes = [C.c_void_p, C.c_size_t]
+    L.mkt_bam_read.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_size_t, C.POINTER(C.c_void_p)]
     _lib = L
     return L
 

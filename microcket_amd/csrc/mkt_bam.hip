@@ -949,8 +949,14 @@ struct mkt_bam {
     uint8_t* d_bam = nullptr; uint64_t bam_len = 0;
     std::string bai;
     uint64_t records = 0;
+    // pinned staging for callers that move files (mkt_bam_window / _commit / _read): two slots, used alternately
+    char* h_io[2] = {nullptr, nullptr};
+    hipEvent_t ev_io[2] = {nullptr, nullptr};
+    bool io_busy[2] = {false, false};
+    int io_slot = 0;
     std::string err;
 };
+constexpr size_t kBamIoCap = (size_t)64 << 20;
 static int bfail(mkt_bam* s, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -1018,6 +1024,7 @@ void mkt_bam_destroy(mkt_bam* s) {
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     if (s->d_text) (void)hipFree(s->d_text);
     if (s->d_bam) (void)hipFree(s->d_bam);
+    for (int k = 0; k < 2; ++k) { if (s->h_io[k]) (void)hipHostFree(s->h_io[k]); if (s->ev_io[k]) (void)hipEventDestroy(s->ev_io[k]); }
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1025,11 +1032,9 @@ const char* mkt_bam_error(const mkt_bam* s) { return s ? s->err.c_str() : ""; }
 
 // The next bytes of the SAM stream (any chunking).  Leading '@' lines are the header; everything from the first other line on
 // is alignment text and goes to the device.
-int mkt_bam_add(mkt_bam* s, const char* bytes, size_t n) {
-    if (!s || (n && !bytes)) return MKT_E_ARG;
+static int bam_add_bytes(mkt_bam* s, const char* bytes, size_t n, bool pinned_async) {
     if (s->ran) return bfail(s, MKT_E_STATE, "add after run");
     BCHK(s, hipSetDevice(s->device));
-    size_t at = 0;
     if (!s->header_done) {
         s->pending.append(bytes, n);
         size_t p = 0;
@@ -1054,9 +1059,50 @@ int mkt_bam_add(mkt_bam* s, const char* bytes, size_t n) {
     }
     int rc = bam_reserve(s, s->len + n + 1);
     if (rc) return rc;
-    if (n - at) BCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes + at, n - at, hipMemcpyHostToDevice, s->stream));
-    BCHK(s, hipStreamSynchronize(s->stream));
-    s->len += n - at;
+    if (n) BCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes, n, hipMemcpyHostToDevice, s->stream));
+    if (!pinned_async) BCHK(s, hipStreamSynchronize(s->stream));       // the caller may reuse `bytes`
+    s->len += n;
+    return MKT_OK;
+}
+int mkt_bam_add(mkt_bam* s, const char* bytes, size_t n) {
+    if (!s || (n && !bytes)) return MKT_E_ARG;
+    return bam_add_bytes(s, bytes, n, false);
+}
+// room for `bytes` of alignment text, so that the buffer does not grow (and get copied) while the stream comes in
+int mkt_bam_reserve(mkt_bam* s, size_t bytes) {
+    if (!s) return MKT_E_ARG;
+    if (s->ran) return bfail(s, MKT_E_STATE, "reserve after run");
+    BCHK(s, hipSetDevice(s->device));
+    return bam_reserve(s, bytes + 1);
+}
+static int bam_io_slot(mkt_bam* s, int k) {
+    if (!s->h_io[k]) {
+        BCHK(s, hipHostMalloc((void**)&s->h_io[k], kBamIoCap, hipHostMallocDefault));
+        BCHK(s, hipEventCreateWithFlags(&s->ev_io[k], hipEventDisableTiming));
+    }
+    if (s->io_busy[k]) { BCHK(s, hipEventSynchronize(s->ev_io[k])); s->io_busy[k] = false; }
+    return MKT_OK;
+}
+// A pinned host buffer for the next bytes of the SAM stream (read a file straight into it), then mkt_bam_commit: the copy to the
+// GPU runs while the caller fills the other buffer.
+int mkt_bam_window(mkt_bam* s, char** buf, size_t* cap) {
+    if (!s || !buf || !cap) return MKT_E_ARG;
+    if (s->ran) return bfail(s, MKT_E_STATE, "window after run");
+    BCHK(s, hipSetDevice(s->device));
+    int rc = bam_io_slot(s, s->io_slot);
+    if (rc) return rc;
+    *buf = s->h_io[s->io_slot]; *cap = kBamIoCap;
+    return MKT_OK;
+}
+int mkt_bam_commit(mkt_bam* s, size_t n) {
+    if (!s || n > kBamIoCap) return MKT_E_ARG;
+    const int k = s->io_slot;
+    if (!s->h_io[k]) return bfail(s, MKT_E_STATE, "commit without window");
+    int rc = bam_add_bytes(s, s->h_io[k], n, true);
+    if (rc) return rc;
+    BCHK(s, hipEventRecord(s->ev_io[k], s->stream));
+    s->io_busy[k] = true;
+    s->io_slot = k ^ 1;
     return MKT_OK;
 }
 // alignment lines that are already on the device (no header lines)
@@ -1094,6 +1140,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         fprintf(stderr, "[mkt_bam] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
     };
+    BCHK(s, hipStreamSynchronize(st));                            // (copies of mkt_bam_commit may still be on their way)
     if (s->len) {
         char last = 0;
         BCHK(s, hipMemcpy(&last, s->d_text + s->len - 1, 1, hipMemcpyDeviceToHost));
@@ -1429,6 +1476,27 @@ int mkt_bam_fetch(mkt_bam* s, int which, uint64_t off, char* out, size_t n) {
     if (off + n > s->bam_len) return bfail(s, MKT_E_ARG, "range past the end of the BAM");
     BCHK(s, hipSetDevice(s->device));
     if (n) BCHK(s, hipMemcpy(out, s->d_bam + off, n, hipMemcpyDeviceToHost));
+    return MKT_OK;
+}
+
+// Result bytes [off, off + n) (n <= 64 MiB) through the pinned buffers: *ptr stays valid until the next call but one.
+int mkt_bam_read(mkt_bam* s, int which, uint64_t off, size_t n, const char** ptr) {
+    if (!s || !ptr) return MKT_E_ARG;
+    if (!s->ran) return bfail(s, MKT_E_STATE, "read before run");
+    if (which == 1) {
+        if (off + n > s->bai.size()) return bfail(s, MKT_E_ARG, "range past the end of the index");
+        *ptr = s->bai.data() + off;
+        return MKT_OK;
+    }
+    if (n > kBamIoCap || off + n > s->bam_len) return bfail(s, MKT_E_ARG, "range past the end of the BAM, or longer than 64 MiB");
+    BCHK(s, hipSetDevice(s->device));
+    const int k = s->io_slot;
+    int rc = bam_io_slot(s, k);
+    if (rc) return rc;
+    if (n) BCHK(s, hipMemcpyAsync(s->h_io[k], s->d_bam + off, n, hipMemcpyDeviceToHost, s->stream));
+    BCHK(s, hipStreamSynchronize(s->stream));
+    *ptr = s->h_io[k];
+    s->io_slot = k ^ 1;
     return MKT_OK;
 }
 
