@@ -40,7 +40,11 @@ struct FastCfg {
     static constexpr int NV16 = (W + 15) / 16;       // 16-byte vectors of the window
     static constexpr int HMW = (NV16 + 63) / 64;     // 64-bit words of the "vector holds a newline" bitmap
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
+#if defined(MKT_HSTRIDE8)
+    static constexpr int HSTRIDE = HEADB + 8;        // row pitch 34 dwords: rows 8-byte aligned (two 64-bit stores per head chunk instead of four dwords)
+#else
     static constexpr int HSTRIDE = HEADB + 4;        // row pitch: 33 dwords, so lanes reading the same column of their own rows hit 32 different banks
+#endif
     static constexpr int HW = LCAP_ * HSTRIDE;       // bytes of the head store
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
@@ -537,6 +541,50 @@ template <class Cfg> MKT_HD void fast_emit_line(const FastState<Cfg>& st, uint32
         for (uint32_t k = 0; k < rl[r]; k += 4u) {
             uint32_t x = state_load4(base, rs[r] + k);
             const uint32_t take = rl[r] - k < 4u ? rl[r] - k : 4u;
+            if (take < 4u) x &= (1u << (8u * take)) - 1u;
+            acc |= (uint64_t)x << (8u * cnt);
+            cnt += take;
+            if (cnt >= 4u) {
+                const uint32_t v = (uint32_t)acc;
+                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) b[q] = (uint8_t)(v >> (8u * q)); first = false; }
+                else *d = v;
+                ++d; acc >>= 32; cnt -= 4u;
+            }
+        }
+    }
+    {   // what is left: cnt (< 4) bytes of the last, shared dword
+        uint8_t* b = reinterpret_cast<uint8_t*>(d);
+        for (uint32_t q = first ? a : 0u; q < cnt; ++q) b[q] = (uint8_t)((uint32_t)acc >> (8u * q));
+    }
+}
+
+// The same for bytes [lo, hi) of the line only: several lanes share one line (the emit phase is a serial byte stream per lane,
+// its length is the phase's critical path).  Every part starts and ends with single bytes like a whole line does.
+template <class Cfg> MKT_HD void fast_emit_part(const FastState<Cfg>& st, uint32_t slot, uint32_t plen, uint8_t* line_dst, uint32_t lo, uint32_t hi) {
+    if (lo >= hi) return;
+    const auto& g = st.u.g;
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(&st);
+    const uint32_t w = (uint32_t)(st.win - base);
+    const uint32_t e0 = g.l_e0[slot], e1 = g.l_e1[slot], e2 = g.l_e2[slot], e3 = g.l_e3[slot];
+    const uint32_t rs[5] = {w + g.l_qa[slot], w + g.l_ca[slot], (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litA[slot][0]) - base),
+                            w + g.l_cb[slot], (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litB[slot][0]) - base)};
+    const uint32_t rb[6] = {0u, e0, e1, e2, e3, plen};            // run r is line bytes [rb[r], rb[r + 1])
+    uint8_t* dst = line_dst + lo;
+    const uint32_t a = (uint32_t)((uintptr_t)dst & 3u);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst - a);            // the aligned dword that holds the part's first byte
+    uint64_t acc = 0;
+    uint32_t cnt = a;                                              // its low `a` bytes belong to whoever writes in front
+    bool first = a != 0u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 5; ++r) {
+        const uint32_t b0 = rb[r] > lo ? rb[r] : lo, b1 = rb[r + 1] < hi ? rb[r + 1] : hi;
+        if (b0 >= b1) continue;
+        const uint32_t src = rs[r] + (b0 - rb[r]), len = b1 - b0;
+        for (uint32_t k = 0; k < len; k += 4u) {
+            uint32_t x = state_load4(base, src + k);
+            const uint32_t take = len - k < 4u ? len - k : 4u;
             if (take < 4u) x &= (1u << (8u * take)) - 1u;
             acc |= (uint64_t)x << (8u * cnt);
             cnt += take;

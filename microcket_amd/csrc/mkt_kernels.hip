@@ -79,6 +79,38 @@ __device__ inline void block_exscan1(uint32_t& a, uint32_t& total, ScanScratch& 
     __syncthreads();
 }
 
+// inclusive scan of one u32 over the wave by data-parallel-primitive adds (row shifts 1, 2, 4, 8 inside each row of 16 lanes, then
+// lane 15 / 31 of a row broadcast into the rows behind): six VALU instructions, no LDS crossbar
+__device__ inline uint32_t wave_iscan32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// exclusive scan of three u32 per thread over the workgroup (the tile sums of k_fast: every total stays far below 2^32)
+// (tail_barrier = false: the caller reaches a barrier of its own before the scratch is used again)
+template <bool tail_barrier = true>
+__device__ inline void block_exscan3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& ta, uint32_t& tb, uint32_t& tc, ScanScratch& sc) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ia = wave_iscan32(a), ib = wave_iscan32(b), ic = wave_iscan32(c);
+    if (lane == 63) { sc.a[wv] = (uint64_t)ia | ((uint64_t)ib << 32); sc.b[wv] = ic; }
+    __syncthreads();
+    uint32_t pa = 0, pb = 0, pc = 0;
+    ta = 0; tb = 0; tc = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint64_t x = sc.a[w];
+        const uint32_t xa = (uint32_t)x, xb = (uint32_t)(x >> 32), xc = (uint32_t)sc.b[w];
+        if (w < wv) { pa += xa; pb += xb; pc += xc; }
+        ta += xa; tb += xb; tc += xc;
+    }
+    a = pa + ia - a; b = pb + ib - b; c = pc + ic - c;
+    if (tail_barrier) __syncthreads();
+}
+
 // exclusive scan of two u64 lanes-values over the workgroup; totals returned to every thread
 __device__ inline void block_exscan2(uint64_t& a, uint64_t& b, uint64_t& ta, uint64_t& tb, ScanScratch& sc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -543,10 +575,8 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             static_assert(Cfg::HMW <= 64, "one bitmap word per lane of one wave");
             uint64_t m = tid < Cfg::HMW ? st.u.m.hitmap[tid] : 0ull;
             const uint32_t cnt = (uint32_t)__popcll(m);
-            uint32_t inc = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)inc, d, 64); if (tid >= d) inc += y; }
-            const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+            const uint32_t inc = wave_iscan32(cnt);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             const uint32_t lead = G.w0 == 0 ? 1u : 0u;             // the block's first line has no newline in front of it
             const uint32_t NLt = total + lead;
             if (NLt > (uint32_t)Cfg::LCAP) {
@@ -606,8 +636,13 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                         }
                     }
                     {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
+#if defined(MKT_HSTRIDE8)
+                        uint2* row = reinterpret_cast<uint2*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + (c << 4)]);
+                        row[0] = make_uint2(x.x, x.y); row[1] = make_uint2(x.z, x.w);
+#else
                         uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + (c << 4)]);
                         row[0] = x.x; row[1] = x.y; row[2] = x.z; row[3] = x.w;
+#endif
                     }
                     uint32_t m = pack16(ws_flags(x.x), ws_flags(x.y), ws_flags(x.z), ws_flags(x.w));
                     if (EDGE && keep < 16u) m &= (1u << keep) - 1u;            // cleared bytes are not whitespace
@@ -693,6 +728,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         {
             auto& g = st.u.g;
             const uint32_t i = first_idx + tid;
+#if defined(MKT_SUMS64)
             uint64_t ca = 0, cb = 0;
             uint32_t info = 0;
             if (i < NLe && !st.abn) {
@@ -720,24 +756,68 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 st.sums.pair_bytes = (uint32_t)tb; st.sums.sam_bytes = tb >> 32;
                 if ((uint32_t)tb > 0xFFFFu) st.abn = AB_PAIR_BYTES;          // 16-bit in-tile offsets
             }
+#else
+            // counts packed 10 bits apiece (<= LCAP each), .pairs bytes, .sam bytes: three 32-bit scans
+            uint32_t cc = 0, cp = 0, cs = 0;
+            uint32_t info = 0;
+            if (i < NLe && !st.abn) {
+                if (i < end_idx) {
+                    info = g.g_info[i];
+                    if (info & GI_START) cc += 1u;
+                    if (info & GI_EMIT) cc += 1u << 10;
+                    if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) cc += 1u << 20;
+                    cp = g.g_plen[i];
+                }
+                if (P.write_sam) cs = fast_line_sam(st, G, i);
+            }
+            uint32_t ec = cc, ep = cp, es = cs, tc, tp, ts;
+            block_exscan3<false>(ec, ep, es, tc, tp, ts, scan);
+            if (tid == 0) {
+                // the tile's totals, and with them at once its output ranges: the claiming atomic is on its way while the other
+                // lanes store their offsets (one barrier fewer than a phase of its own)
+                st.sums.groups = tc & 0x3FFu; st.sums.emitted = (tc >> 10) & 0x3FFu; st.sums.sc = (tc >> 20) & 0x3FFu;
+                st.sums.pair_bytes = tp; st.sums.sam_bytes = ts;
+                if (tp > 0xFFFFu) st.abn = AB_PAIR_BYTES;                    // 16-bit in-tile offsets
+                else if (!st.abn) {
+                    const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
+                    st.region_id = region;
+                    if (e) lds_or(&st.abn, e << 8);
+                    a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
+                }
+            }
+            if (i < NLe && !(st.abn & 0xFFu)) {                  // (bits 8.. are lane 0's claim errors, possibly set by now)
+                g.x_sam[i] = es;
+                if (i < end_idx) {
+                    g.x_grp[i] = (uint8_t)(ec & 0xFFu); g.x_sc[i] = (uint8_t)((ec >> 20) & 0xFFu); g.x_emit[i] = (uint8_t)((ec >> 10) & 0xFFu);
+                    g.x_pair[i] = (uint16_t)(ep & 0xFFFFu);
+                    if (info & GI_EMIT) g.em_idx[(ec >> 10) & 0xFFu] = (uint8_t)i;
+                }
+            }
+#endif
         }
         __syncthreads();
         STAMP(6);
         STOP_AFTER(6)
         if (PF > 0 && t + gridDim.x < a.ntiles) prefetch(t + gridDim.x);
-        if (st.abn) {                                         // leave the whole tile to the generic kernel
+#if defined(MKT_SUMS64)
+        if (st.abn) {
+#else
+        if (st.abn & 0xFFu) {                                 // leave the whole tile to the generic kernel
+#endif
             if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
             __syncthreads();
             continue;
         }
 
-        // ---- output ranges --------------------------------------------------------------------------
+        // ---- output ranges: claimed by lane 0 at the end of the sums phase (above)
+#if defined(MKT_SUMS64)
         if (tid == 0) {
             const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
             st.region_id = region;
             if (e) lds_or(&st.abn, e << 8);
         } else if (tid == 4) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
         __syncthreads();
+#endif
         STAMP(7);
         STOP_AFTER(7)
         if (MKT_TOUCH == 3) touch_next(t + gridDim.x);
@@ -760,10 +840,24 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         // .pairs: one lane per reported pair writes its whole line (fast_emit_line)
         if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
             const auto& g = st.u.g;
+#ifndef MKT_EMIT_PARTS
+#define MKT_EMIT_PARTS 1
+#endif
+#if MKT_EMIT_PARTS == 1
             for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted; e += NT) {      // (the two waves the accounting left idle)
                 const uint32_t i = g.em_idx[e];
                 fast_emit_line(st, g.g_slot[i], g.g_plen[i], dst + g.x_pair[i]);
             }
+#else
+            // MKT_EMIT_PARTS lanes per line, each a contiguous share of its bytes
+            for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted * (uint32_t)MKT_EMIT_PARTS; e += NT) {
+                const uint32_t i = g.em_idx[e / (uint32_t)MKT_EMIT_PARTS], part = e % (uint32_t)MKT_EMIT_PARTS;
+                const uint32_t plen = g.g_plen[i];
+                const uint32_t lo = (mul24(plen, part) / (uint32_t)MKT_EMIT_PARTS + 3u) & ~3u, hi0 = (mul24(plen, part + 1u) / (uint32_t)MKT_EMIT_PARTS + 3u) & ~3u;
+                const uint32_t hi = part + 1u == (uint32_t)MKT_EMIT_PARTS ? plen : (hi0 < plen ? hi0 : plen);
+                fast_emit_part(st, g.g_slot[i], plen, dst + g.x_pair[i], lo < plen ? lo : plen, hi);
+            }
+#endif
         }
         __syncthreads();
         // counters and error bits of the tile are final here; flushed once per workgroup (9 global atomics per TILE on one
