@@ -837,8 +837,23 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             fast_last(st, G, &a.tile_last[t], i);
         }
 #endif
-        // .pairs: one lane per reported pair writes its whole line (fast_emit_line)
-        if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
+        // .pairs: one lane per reported pair writes its whole line (fast_emit_line).  Experiment switch MKT_EMIT_STAGED: into LDS
+        // first (the dead parse records), then out as aligned 16-byte vectors of the tile's ONE contiguous range
+        constexpr uint32_t STAGE_CAP = (uint32_t)sizeof(st.rc.f) & ~15u;
+#if defined(MKT_EMIT_STAGED)
+        const bool staged = total != 0u && total + 16u <= STAGE_CAP;
+#else
+        const bool staged = false;                             // (measured: 1.6 % slower than the direct stores)
+#endif
+        uint8_t* const stage = reinterpret_cast<uint8_t*>(&st.rc.f);
+        const uint32_t a16 = (uint32_t)((uintptr_t)dst & 15u);
+        if (total && st.base.pair_bytes + total <= s_out.pairs_cap && staged) {
+            const auto& g = st.u.g;
+            for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted; e += NT) {      // (the two waves the accounting left idle)
+                const uint32_t i = g.em_idx[e];
+                fast_emit_line(st, g.g_slot[i], g.g_plen[i], stage + a16 + g.x_pair[i]);
+            }
+        } else if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
             const auto& g = st.u.g;
 #ifndef MKT_EMIT_PARTS
 #define MKT_EMIT_PARTS 1
@@ -864,6 +879,20 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         // cache line would queue up behind each other)
         if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
         if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
+        if (staged && st.base.pair_bytes + total <= s_out.pairs_cap) {
+            // staged bytes [a16, a16 + total) <-> dst[0, total): vector v is staging [16 v, 16 v + 16) = (dst - a16)[16 v, ...)
+            uint8_t* const gbase = dst - a16;
+            const uint32_t endb = a16 + total, nvec = (endb + 15u) >> 4;
+            for (uint32_t v = (uint32_t)tid; v < nvec; v += NT) {
+                const uint32_t b0 = v << 4;
+                if (b0 >= a16 && b0 + 16u <= endb) *reinterpret_cast<uint4*>(gbase + b0) = *reinterpret_cast<const uint4*>(stage + b0);
+                else {
+                    const uint32_t lo = b0 > a16 ? b0 : a16, hi = b0 + 16u < endb ? b0 + 16u : endb;
+                    for (uint32_t k = lo; k < hi; ++k) gbase[k] = stage[k];
+                }
+            }
+            if (P.write_sam) __syncthreads();                       // (the .sam copy below builds its line list in the same LDS)
+        }
 #if defined(MKT_SAM_LINEWISE)
         if (P.write_sam && st.sums.sam_bytes) {
             const uint64_t gos = st.base.sam_bytes;
