@@ -839,8 +839,8 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
 #endif
         // .pairs: one lane per reported pair writes its whole line (fast_emit_line).  Experiment switch MKT_EMIT_STAGED: into LDS
         // first (the dead parse records), then out as aligned 16-byte vectors of the tile's ONE contiguous range
-        constexpr uint32_t STAGE_CAP = (uint32_t)sizeof(st.rc.f) & ~15u;
 #if defined(MKT_EMIT_STAGED)
+        constexpr uint32_t STAGE_CAP = (uint32_t)sizeof(st.rc.f) & ~15u;
         const bool staged = total != 0u && total + 16u <= STAGE_CAP;
 #else
         const bool staged = false;                             // (measured: 1.6 % slower than the direct stores)
