@@ -489,6 +489,9 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         }
     };
     if (PF > 0 && blockIdx.x < a.ntiles) prefetch(blockIdx.x);      // (experiment switch; assumes the default tile order)
+    // the output pointers once per workgroup: the per-tile limits in s_out are all rewritten by every claim (the argument block
+    // lives in scratch memory by now -- five dependent loads that used to sit in front of lane 0's scan of EVERY tile)
+    if (tid0 == 0) s_out = a.out;
     uint32_t rot = 0;
 #ifndef MKT_TOUCH
 #define MKT_TOUCH 0          // 1 / 2 / 3: touch the NEXT tile's window (one dword per 128-byte line) before parse / groups / emit
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
         // (no barrier: the previous tile ended on one, and nothing below reads what lane 0 resets here before the barrier
         // that ends the scan phase)
-        if (tid == 0) { s_out = a.out; fast_reset(st); }
+        if (tid == 0) fast_reset(st);
         STAMP(0);
         const TileGeom G = fast_geom<Cfg>(t, n);
         const uint32_t wlen = G.w1 - G.w0;
