@@ -512,7 +512,9 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
 #else
     const uint32_t t_first = blockIdx.x;
 #endif
-    for (uint32_t t = t_first; t < a.ntiles; t += gridDim.x) {
+    uint32_t gdim = gridDim.x;                                   // (read once: the dispatch packet is a scalar memory load away)
+    asm volatile("" : "+s"(gdim));
+    for (uint32_t t = t_first; t < a.ntiles; t += gdim) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
         // (no barrier: the previous tile ended on one, and nothing below reads what lane 0 resets here before the barrier
