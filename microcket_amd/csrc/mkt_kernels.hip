@@ -25,7 +25,7 @@
 #define MKT_LEAN_LCAP kLeanLCAP
 #endif
 #ifndef MKT_LOAD_BATCH
-#define MKT_LOAD_BATCH 7
+#define MKT_LOAD_BATCH 14     // (every window vector of a lane in flight at once: 14 x 16 bytes; 7 measured 0.7 % slower)
 #endif
 
 namespace mkt {
