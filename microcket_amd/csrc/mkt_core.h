@@ -20,6 +20,15 @@
 #define MKT_HD inline
 #endif
 
+// Output pointers travel through LDS (OutPtrs), where the compiler loses their address space and falls back to FLAT stores; a
+// FLAT instruction also counts on the LDS counter (lgkmcnt), so every later LDS read of the lane waits for it.  The outputs
+// are global memory: say so.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MKT_GLOBAL(T, p) ((__attribute__((address_space(1))) T*)(p))
+#else
+#define MKT_GLOBAL(T, p) ((T*)(p))
+#endif
+
 namespace mkt {
 
 constexpr int kMinClip = 20;          // pairutil.h:54

@@ -421,7 +421,7 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
     if (counter) lds_add(&st.cnt[counter], 1u);
     if (counter == C_SELFCIRCLE) {
         uint64_t k = (uint64_t)st.base.sc + st.u.g.x_sc[i];
-        if (k < out.sc_cap) out.sc[k] = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
+        if (k < out.sc_cap) *MKT_GLOBAL(uint64_t, out.sc + k) = ((uint64_t)tile << 32) | st.u.g.x_grp[i];
         else lds_or(&st.abn, E_SC_CAP << 8);          // reported as an error bit by the kernel (OR: other lanes and the claim step set bits too)
     }
     if ((info & GI_EMIT) && out.keys) {               // extension: duplicate-marking key of this pair
@@ -435,7 +435,7 @@ template <class Cfg> MKT_HD void fast_account(FastState<Cfg>& st, const OutPtrs&
             const uint32_t sa = fast_chr_slot(st, out.chr, tv, g.l_ca[slot], (uint32_t)(g.l_e1[slot] - g.l_e0[slot] - 1u), &err);
             const uint32_t sb = fast_chr_slot(st, out.chr, tv, g.l_cb[slot], (uint32_t)(g.l_e3[slot] - g.l_e2[slot] - 1u), &err);
             const uint32_t lane = out.key_lanes ? qname_lane(tv, (uint32_t)st.off16[i] + st.qn_off[i], st.qn_len[i]) : 0u;
-            out.keys[k] = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i], lane);
+            *MKT_GLOBAL(KeyRec, out.keys + k) = make_key(sa, g.l_posA[slot], sb, g.l_posB[slot], (info & GI_SA_MINUS) != 0, (info & GI_SB_MINUS) != 0, tile, g.x_emit[i], lane);
             if (err) lds_or(&st.abn, err << 8);
         } else lds_or(&st.abn, E_SC_CAP << 8);
     }
@@ -546,15 +546,15 @@ template <class Cfg> MKT_HD void fast_emit_line(const FastState<Cfg>& st, uint32
             cnt += take;
             if (cnt >= 4u) {
                 const uint32_t v = (uint32_t)acc;
-                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) b[q] = (uint8_t)(v >> (8u * q)); first = false; }
-                else *d = v;
+                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) *MKT_GLOBAL(uint8_t, b + q) = (uint8_t)(v >> (8u * q)); first = false; }
+                else *MKT_GLOBAL(uint32_t, d) = v;
                 ++d; acc >>= 32; cnt -= 4u;
             }
         }
     }
     {   // what is left: cnt (< 4) bytes of the last, shared dword
         uint8_t* b = reinterpret_cast<uint8_t*>(d);
-        for (uint32_t q = first ? a : 0u; q < cnt; ++q) b[q] = (uint8_t)((uint32_t)acc >> (8u * q));
+        for (uint32_t q = first ? a : 0u; q < cnt; ++q) *MKT_GLOBAL(uint8_t, b + q) = (uint8_t)((uint32_t)acc >> (8u * q));
     }
 }
 
@@ -590,15 +590,15 @@ template <class Cfg> MKT_HD void fast_emit_part(const FastState<Cfg>& st, uint32
             cnt += take;
             if (cnt >= 4u) {
                 const uint32_t v = (uint32_t)acc;
-                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) b[q] = (uint8_t)(v >> (8u * q)); first = false; }
-                else *d = v;
+                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) *MKT_GLOBAL(uint8_t, b + q) = (uint8_t)(v >> (8u * q)); first = false; }
+                else *MKT_GLOBAL(uint32_t, d) = v;
                 ++d; acc >>= 32; cnt -= 4u;
             }
         }
     }
     {   // what is left: cnt (< 4) bytes of the last, shared dword
         uint8_t* b = reinterpret_cast<uint8_t*>(d);
-        for (uint32_t q = first ? a : 0u; q < cnt; ++q) b[q] = (uint8_t)((uint32_t)acc >> (8u * q));
+        for (uint32_t q = first ? a : 0u; q < cnt; ++q) *MKT_GLOBAL(uint8_t, b + q) = (uint8_t)((uint32_t)acc >> (8u * q));
     }
 }
 

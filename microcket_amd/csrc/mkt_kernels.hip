@@ -957,8 +957,8 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             const uint32_t head0 = (uint32_t)((16u - ((uintptr_t)dbase & 15u)) & 15u);
             const uint32_t head = head0 < total ? head0 : total;
             const uint32_t nv = (total - head) >> 4, tail0 = head + (nv << 4);
-            if ((uint32_t)tid < head) { const uint32_t k = line_of((uint32_t)tid); dbase[tid] = tbase[es[k] + (uint32_t)tid - eo[k]]; }
-            if ((uint32_t)tid < total - tail0) { const uint32_t d = tail0 + (uint32_t)tid, k = line_of(d); dbase[d] = tbase[es[k] + d - eo[k]]; }
+            if ((uint32_t)tid < head) { const uint32_t k = line_of((uint32_t)tid); *MKT_GLOBAL(uint8_t, dbase + tid) = tbase[es[k] + (uint32_t)tid - eo[k]]; }
+            if ((uint32_t)tid < total - tail0) { const uint32_t d = tail0 + (uint32_t)tid, k = line_of(d); *MKT_GLOBAL(uint8_t, dbase + d) = tbase[es[k] + d - eo[k]]; }
             for (uint32_t v = (uint32_t)tid; v < nv; v += NT) {
                 const uint32_t d = head + (v << 4);
                 const uint32_t k = line_of(d);
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                     }
                     x = make_uint4(q0, q1, q2, q3);
                 }
-                *reinterpret_cast<uint4*>(dbase + d) = x;
+                *MKT_GLOBAL(uint4, dbase + d) = x;
             }
         }
 #endif
