@@ -39,17 +39,26 @@ struct ScanScratch { uint64_t a[NT / 64], b[NT / 64]; };
 // Diagnostic build only (-DMKT_STAMPS): per-phase shader-clock shares, accumulated by lane 0 of
 // every tile into a.stamps[phase].  Never compiled into the shipped library.
 #if defined(MKT_STAMPS)
+// (accumulated in registers of lane 0 and added to a.stamps once per workgroup: an atomic per phase and tile would itself be
+//  the longest thing on lane 0's path)
+#define STAMP_DECL() unsigned long long stamp_prev_ = 0, stamp_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(k)                                                                        \
     do {                                                                                \
         if (tid == 0 && a.stamps) {                                                     \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
-            if ((k) > 0) atomicAdd(&a.stamps[(k)], now_ - stamp_prev_);                 \
+            if ((k) > 0) stamp_acc_[(k)] += now_ - stamp_prev_;                         \
             stamp_prev_ = now_;                                                         \
         }                                                                               \
     } while (0)
+#define STAMP_FLUSH(t0_)                                                                \
+    do {                                                                                \
+        if ((t0_) == 0 && a.stamps) for (int k_ = 1; k_ < 16; ++k_) if (stamp_acc_[k_]) atomicAdd(&a.stamps[k_], stamp_acc_[k_]); \
+    } while (0)
 #define STOP_AFTER(k) if (a.debug_stop == (k)) { __syncthreads(); continue; }
 #else
+#define STAMP_DECL() do { } while (0)
 #define STAMP(k) do { } while (0)
+#define STAMP_FLUSH(t0_) do { } while (0)
 #define STOP_AFTER(k)
 #endif
 
@@ -249,9 +258,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
     const uint32_t region = a.nregions > 1 ? (blockIdx.x & (uint32_t)(a.nregions - 1)) : 0u;
     uint16_t* nlmask = reinterpret_cast<uint16_t*>(st.u.m.nlm);
     uint16_t* wsmask = reinterpret_cast<uint16_t*>(st.u.m.wsm);
-#if defined(MKT_STAMPS)
-    unsigned long long stamp_prev_ = 0;
-#endif
+    STAMP_DECL();
 
     for (;;) {
         if (tid == 0) {
@@ -435,6 +442,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
         if (tid == 0 && st.err) atomicOr(&a.res->err, st.err);
         __syncthreads();
     }
+    STAMP_FLUSH(tid);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -456,9 +464,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
     const uint32_t n = a.n;
     __shared__ OutPtrs s_out;
     const uint32_t region = blockIdx.x & (uint32_t)(a.nregions - 1);
-#if defined(MKT_STAMPS)
-    unsigned long long stamp_prev_ = 0;
-#endif
+    STAMP_DECL();
 
     __shared__ uint32_t wg_cnt[C_COUNT];                  // this workgroup's share of the block's counters
     if (tid0 < (int)C_COUNT) wg_cnt[tid0] = 0;
@@ -658,6 +664,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             else heads(std::false_type{});
         }
         __syncthreads();
+        STAMP(9);
         STOP_AFTER(9)
         if (MKT_TOUCH == 1) touch_next(t + gridDim.x);
 
@@ -713,6 +720,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
 #endif
         }
         __syncthreads();
+        STAMP(10);
 #if defined(MKT_GROUP1)
         const uint32_t sc0 = st.start_cnt[0], sc1 = sc0 + st.start_cnt[1], sc2 = sc1 + st.start_cnt[2], nst = sc2 + st.start_cnt[3];
         auto start_line = [&](uint32_t L) -> uint32_t {
@@ -880,6 +888,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
 #endif
         }
         __syncthreads();
+        STAMP(11);
         // counters and error bits of the tile are final here; flushed once per workgroup (9 global atomics per TILE on one
         // cache line would queue up behind each other)
         if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
@@ -999,6 +1008,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         STAMP(8);
     }
     if (tid0 < (int)C_COUNT && wg_cnt[tid0]) atomicAdd(&a.res->counters[tid0], wg_cnt[tid0]);
+    STAMP_FLUSH(tid0);
 }
 
 // After the tiles, step 1 (one workgroup per 1024 tiles): exclusive scan of the per-tile group counts

@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import microcket_amd as m
 
 # STAMP(k) adds the time since STAMP(k-1)
-LABEL = {1: "load + bitmaps", 2: "line table", 3: "parse", 4: "group start", 5: "group walk + classify", 6: "tile sums", 7: "look-back", 8: "emit"}
+LABEL = {1: "scan (loads + bitmaps)", 2: "line table", 9: "heads", 3: "parse", 10: "group starts", 4: "groups (classify)", 5: "-", 6: "sums + claim", 7: "-", 11: "account + emit", 8: "tail (.sam copy, end barrier)"}
+ORDER = [1, 2, 9, 3, 10, 4, 6, 11, 8]
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 sam = len(sys.argv) > 2 and sys.argv[2] == "yes"
@@ -25,8 +26,8 @@ for _ in range(2):
         ctx.submit_device(p, n)
     ctx.sync()
     ctx.L.mkt_debug_stamps(ctx.h, out)
-tot = sum(out[1:9])
+tot = sum(out[k] for k in ORDER)
 t = ctx.timing()
 print(f"pairs {ds.total_groups} bytes {ds.total_bytes} kernel_ms(1 pass) {t.tile_kernel_ms:.2f}  -> {ds.total_bytes / t.tile_kernel_ms / 1e6:.1f} GB/s")
-for k in range(1, 9):
+for k in ORDER:
     print(f"{LABEL[k]:24s} {out[k]:16d} {100.0 * out[k] / tot:6.2f} %")
