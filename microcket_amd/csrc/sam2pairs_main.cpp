@@ -32,8 +32,6 @@
 #include <string>
 #include <thread>
 #include <vector>
-#include <fcntl.h>
-#include <linux/falloc.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include "../../include/mkt.h"
@@ -135,27 +133,6 @@ int main(int argc, char* argv[]) {
     struct stat ssb;
     const bool sam_regular = fsam && fstat(sam_fd, &ssb) == 0 && S_ISREG(ssb.st_mode);
     std::atomic<int> write_failed{0}, drain_rc{0};
-    // The .sam file grows by gigabytes per second; on tmpfs (the driver's scratch) and on extent file systems the allocation of
-    // fresh pages / blocks is the slow half of a write.  A helper thread allocates ahead of the writer (fallocate, file size
-    // untouched), at most 2 GiB in front of it and never more than the input is long; the file is cut to its length at the end.
-    std::atomic<long long> sam_written{0};
-    std::atomic<int> prealloc_stop{0};
-    std::thread prealloc;
-    if (sam_regular && !((e = getenv("MKT_PREALLOC")) && e[0] == '0')) {
-        struct stat isb;
-        const long long limit = fstat(fileno(fin), &isb) == 0 && S_ISREG(isb.st_mode) ? (long long)isb.st_size : (1ll << 62);
-        prealloc = std::thread([&, limit]() {
-            const long long step = 256ll << 20, ahead = 2ll << 30;
-            long long done = 0;
-            while (!prealloc_stop) {
-                const long long want = sam_written.load() + ahead, target = want < limit ? want : limit;
-                if (done >= target) { if (done >= limit) break; usleep(500); continue; }
-                const long long len = target - done < step ? target - done : step;
-                if (fallocate(sam_fd, FALLOC_FL_KEEP_SIZE, (off_t)done, (off_t)len) != 0) break;      // not supported here: plain writes do
-                done += len;
-            }
-        });
-    }
     std::thread writer([&]() {
         off_t sam_off = 0;
         for (;;) {
@@ -197,7 +174,6 @@ int main(int argc, char* argv[]) {
                         }
                     } else if (!write_all(sam_fd, o.sam, o.sam_len)) write_failed = 1;
                     sam_off += (off_t)o.sam_len;
-                    sam_written = (long long)sam_off;
                 }
             }
             if (done) break;
@@ -207,8 +183,6 @@ int main(int argc, char* argv[]) {
         mkt_stats tmp;
         (void)mkt_finish(ctx, 1, 0, 0, &tmp);
         writer.join();
-        prealloc_stop = 1;
-        if (prealloc.joinable()) prealloc.join();
         return code;
     };
     // Input goes straight into the library's pinned block (no staging copy).  A regular file is read by a few threads
@@ -271,11 +245,6 @@ int main(int argc, char* argv[]) {
     rc = mkt_finish(ctx, 1, 0, 0, &st);
     mark("finish");
     writer.join();
-    prealloc_stop = 1;
-    if (prealloc.joinable()) {
-        prealloc.join();
-        if (ftruncate(sam_fd, (off_t)sam_written.load()) != 0 && !write_failed) write_failed = 1;      // releases what was allocated past the end
-    }
     mark("outputs written");
     if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }
     if (drain_rc) { std::cerr << "Error: " << mkt_strerror(drain_rc) << ": " << mkt_last_error(ctx) << "\n"; return 21; }

@@ -47,7 +47,6 @@ run("mi355x sam=no (first run)", m.exe_path(), "no", {"MKT_VERBOSE": "1"})
 a = run("mi355x sam=no", m.exe_path(), "no", {"MKT_VERBOSE": "1"}, reps=2)
 run("mi355x sam=no, stdout to a /dev/shm file", m.exe_path(), "no", reps=2, out="file")
 b = run("mi355x sam=yes", m.exe_path(), "yes", {"MKT_VERBOSE": "1"}, reps=2)
-run("mi355x sam=yes, no preallocation of the .sam", m.exe_path(), "yes", {"MKT_PREALLOC": "0"}, reps=2)
 if sweep:
     for mb in (16, 32, 128, 256):
         run(f"mi355x sam=no MKT_BLOCK_MB={mb}", m.exe_path(), "no", {"MKT_BLOCK_MB": str(mb)}, reps=2)
