@@ -247,7 +247,8 @@ int mkt_rmdup_fetch(mkt_rmdup* r, int which /* 0: read 1 or the interleaved stre
  * (sorted = 0: `samtools view -b`) or in coordinate order with @HD SO:coordinate and a .bai index (sorted = 1: view | sort,
  * index).  level 0 stores the blocks, 1 deflates them on the GPU with LZ77 + the fixed Huffman codes, >= 2 with codes built per block.  Formats follow the
  * SAM/BAM specification (hts-specs SAMv1 4.1, 4.2, 5.2) and RFC 1951 / 1952; samtools ships with the reference only as a
- * prebuilt binary that is never run, so byte parity with it is unpinned.  Drop-in for the process contract:
+ * prebuilt binary that is never run, so byte parity with it is unpinned.  No .bai is made (bai_bytes = 0) when a
+ * reference is longer than 2^29 bases, the limit of that format.  Drop-in for the process contract:
  * bin/sam2bam (microcket_amd/csrc/sam2bam_main.cpp). */
 typedef struct mkt_bam mkt_bam;
 int mkt_bam_create(int device, mkt_bam** out);

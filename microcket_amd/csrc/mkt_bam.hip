@@ -1342,9 +1342,11 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
     drop(d_comp);
     mark("pack");
 
-    // ---- BAI (coordinate order only)
+    // ---- BAI (coordinate order only; the format ends at 2^29 bases per reference -- longer ones would need a CSI index: none is made then)
     s->bai.clear();
-    if (sorted) {
+    bool bai_ok = true;
+    for (uint32_t i = 0; i < nref; ++i) if (lens[i] > (1u << 29)) bai_ok = false;
+    if (sorted && bai_ok) {
         std::vector<uint64_t> lin_off(nref + 1, 0);
         for (uint32_t i = 0; i < nref; ++i) lin_off[i + 1] = lin_off[i] + ((uint64_t)lens[i] >> 14) + 2;
         const uint64_t nlin = lin_off[nref];

@@ -201,6 +201,9 @@ def test_errors_are_reported():
             m.sam_to_bam(hdr + ok + bad)
     bam_b, bai_b, n = m.sam_to_bam(hdr + ok)
     assert n == 1
+    big = b"@SQ\tSN:chrBig\tLN:600000000\n"                          # beyond the BAI format: a BAM, but no index
+    bam_b, bai_b, n = m.sam_to_bam(big + b"r\t0\tchrBig\t550000000\t0\t1M\t*\t0\t0\tA\tI\n")
+    assert n == 1 and bai_b == b"" and bamio.Bam(bam_b).records[0][2]["pos"] == 549999999
     bam_b, bai_b, n = m.sam_to_bam(hdr)                               # header only
     assert n == 0 and bamio.Bam(bam_b).refs == [("chr1", 1000)]
     bam_b, bai_b, n = m.sam_to_bam(b"")
