@@ -22,6 +22,9 @@ per launch over its HIP-event launch duration, against 8 TB/s HBM.
 oracle/Makefile) timed on this host on a bounded sample of the same data (first blocks).
 `end_to_end` (N = 1): SURVEY.md 8(d)'s metric -- the drop-in executable against the reference on that same sample FILE,
 process start to exit, sam=no and sam=yes; `speedup_vs_cpu_baseline` is that like-for-like ratio.
+`--config C2|C3|C4|C5` picks BASELINE.json's configs[1..4]: pairs per GPU, read length, genome names, lanes and the lane-scoped
+duplicate key (the driver's -b); C2 is the default, C3 / C5 are the shapes of the 8- and 4-GPU configs (per-GPU share).
+`c4_unc100`, `c5_mm10_4lanes` (N = 1): the C4 / C5 shapes as resident legs with their own k_fast roofline.
 `sam_yes`, `flash` (N = 1): the same resident path with the .sam pass-through on / in stitched mode, each with its own
 k_fast roofline.  `roofline.traffic` is imported from the committed rocprofv3 --pmc passes (profiles/), not measured in
 this process.
@@ -47,7 +50,8 @@ def log(*a):
 def cpu_baseline(ctx, ds, sample_groups, threads, mode="unc"):
     """Times the reference (or, if absent, the C restatement) on the first blocks of the data set, and -- on the SAME file in
     /dev/shm -- the drop-in executable (wall clock including process start, file reads, PCIe both ways and all writes):
-    SURVEY.md 8(d)'s end-to-end metric, sam=no and sam=yes.  Returns (cpu_baseline, end_to_end)."""
+    SURVEY.md 8(d)'s end-to-end metric, sam=no and sam=yes, from a regular file and through a pipe (`cat file | exe /dev/stdin`,
+    the driver's real input surface, microcket:479-506).  Returns (cpu_baseline, end_to_end)."""
     ref = os.path.join(ROOT, "oracle", "_ref", "sam2pairs.ref")
     port = os.path.join(ROOT, "oracle", "_build", "sam2pairs_oracle")
     exe, kind = (ref, "reference") if os.path.exists(ref) else (port, "port")
@@ -68,46 +72,57 @@ def cpu_baseline(ctx, ds, sample_groups, threads, mode="unc"):
                 if groups >= sample_groups:
                     break
 
-        def run(binary, nthreads, sam, out):
+        def run(binary, nthreads, sam, pipe=False):
+            args = [binary, "/dev/stdin" if pipe else path, mode, os.path.join(d, "out"), str(nthreads), "0.5", "10", sam]
             t0 = time.time()
-            with open(out, "wb") as o:
-                rc = subprocess.run([binary, path, mode, os.path.join(d, "out"), str(nthreads), "0.5", "10", sam], stdout=o,
-                                    stderr=subprocess.PIPE).returncode
+            with open(os.devnull, "wb") as o:
+                if pipe:
+                    cat = subprocess.Popen(["cat", path], stdout=subprocess.PIPE)
+                    rc = subprocess.run(args, stdin=cat.stdout, stdout=o, stderr=subprocess.PIPE).returncode
+                    cat.stdout.close()
+                    rc = rc or cat.wait()
+                else:
+                    rc = subprocess.run(args, stdout=o, stderr=subprocess.PIPE).returncode
             return rc, time.time() - t0
 
-        rc, dt = run(exe, threads, "no", os.devnull)
-        if rc != 0:
+        def times(binary, nthreads, sam, pipe, reps):
+            ts = []
+            for _ in range(reps):
+                rc, dt = run(binary, nthreads, sam, pipe)
+                if rc != 0:
+                    return None
+                ts.append(dt)
+            return ts
+
+        tref = times(exe, threads, "no", False, 2)
+        if not tref:
             return None, None
+        dt = min(tref)
         cpu = {"value": groups / dt, "unit": "read-pairs/s", "cores": threads if kind == "reference" else 1, "kind": kind,
-               "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input in /dev/shm, sam=no, thread={threads}, {dt:.1f} s",
+               "sample": f"first {groups} pairs ({nbytes / 1e9:.2f} GB SAM) of the same data set, file input in /dev/shm, sam=no, thread={threads}, "
+                         f"best of {len(tref)} runs ({', '.join('%.1f' % t for t in tref)} s)",
                "host_cpus": os.cpu_count()}
         many = min(os.cpu_count() or 1, 64)
         if kind == "reference" and many > threads:              # also at thread = min(nproc, 64)
-            rc2, dt2 = run(exe, many, "no", os.devnull)
-            if rc2 == 0:
-                cpu["more_threads"] = {"cores": many, "value": groups / dt2, "seconds": dt2}
+            t2 = times(exe, many, "no", False, 1)
+            if t2:
+                cpu["more_threads"] = {"cores": many, "value": groups / t2[0], "seconds": t2[0]}
         e2e = None
         mine = m.exe_path()
         if os.path.exists(mine):
-            e2e = {"unit": "read-pairs/s", "what": "the sam2pairs executables on the same file: wall clock from process start to exit, "
-                   "input read from /dev/shm, stdout to /dev/null, side files to /dev/shm; never `value`",
+            e2e = {"unit": "read-pairs/s", "what": "the sam2pairs executables on the same input: wall clock from process start to exit, "
+                   "input from a file in /dev/shm (sam_*) or through `cat file | exe /dev/stdin` (pipe_*), stdout to /dev/null, side files to "
+                   "/dev/shm; best run of each side, every run listed; never `value`",
                    "sample_pairs": groups, "sample_bytes": nbytes}
-            for sam in ("no", "yes"):
-                best = None
-                for _ in range(2):
-                    rcm, dtm = run(mine, threads, sam, os.devnull)
-                    if rcm == 0 and (best is None or dtm < best):
-                        best = dtm
-                if sam == "no":
-                    dref = dt
-                else:
-                    rcr, dref = run(exe, threads, "yes", os.devnull)
-                    if rcr != 0:
-                        dref = None
-                if best is not None:
-                    e2e["sam_" + sam] = {"mi355x": groups / best, "mi355x_seconds": best, "mi355x_GBps": nbytes / best / 1e9,
-                                         "cpu_" + kind: (groups / dref) if dref else None, "cpu_seconds": dref,
-                                         "speedup": (dref / best) if dref else None}
+            for key, sam, pipe, reps_ref in (("sam_no", "no", False, 0), ("sam_yes", "yes", False, 1), ("pipe_no", "no", True, 1), ("pipe_yes", "yes", True, 1)):
+                tm = times(mine, threads, sam, pipe, 3 if not pipe else 2)
+                tr = tref if key == "sam_no" else times(exe, threads, sam, pipe, reps_ref)
+                if tm:
+                    best, dref = min(tm), (min(tr) if tr else None)
+                    e2e[key] = {"mi355x": groups / best, "mi355x_seconds": best, "mi355x_GBps": nbytes / best / 1e9, "mi355x_runs_s": tm,
+                                "cpu_" + kind: (groups / dref) if dref else None, "cpu_seconds": dref, "cpu_runs_s": tr,
+                                "speedup": (dref / best) if dref else None,
+                                "speedup_min_max": [min(tr) / max(tm), max(tr) / min(tm)] if tr else None}
         return cpu, e2e
     finally:
         try:
@@ -118,20 +133,31 @@ def cpu_baseline(ctx, ds, sample_groups, threads, mode="unc"):
             pass
 
 
-def resident_leg(m, local, mode, sam, pairs, block_groups, read_len, steps, warmup, seed, tiles, barrier):
-    """One more resident workload on its own context + data set (sam=yes, flash mode): pairs/s and the k_fast roofline."""
-    ctx = m.Context(mode, 0.5, 10, sam, 8, device=local, tiles=tiles)
-    ds = ctx.dataset(seed, 0 if mode == "unc" else 1, pairs, block_groups, genome=0, read_len=read_len, lanes=1, tail_group=True)
+def resident_leg(m, local, mode, sam, pairs, block_groups, read_len, steps, warmup, seed, tiles, barrier, genome=0, lanes=1, dedup=False, what=""):
+    """One more resident workload on its own context + data set (sam=yes, flash mode, the C4 / C5 shapes): pairs/s and the k_fast
+    roofline.  dedup: every step also marks duplicates (lane-scoped when lanes > 1: the driver's -b) and counts chromosome pairs."""
+    ext = (m.EXT_KEYS | (m.EXT_LANES if lanes > 1 else 0)) if dedup else 0
+    ctx = m.Context(mode, 0.5, 10, sam, 8, device=local, tiles=tiles, extensions=ext)
+    ds = ctx.dataset(seed, 0 if mode == "unc" else 1, pairs, block_groups, genome=genome, read_len=read_len, lanes=lanes, tail_group=True)
+    extra = {}
+
+    def one_step():
+        if dedup:
+            ctx.reset()
+        for (p, n, _g) in ds.blocks:
+            ctx.submit_device(p, n)
+        if dedup:
+            tot, dups, _ = ctx.ext_dedup(True, want_flags=False)
+            rows = ctx.ext_chrstat(True)
+            extra.update(reported_pairs=tot, duplicates=dups, chrstat_rows=len(rows.splitlines()))
     try:
         for _ in range(max(warmup, 1)):
-            for (p, n, _g) in ds.blocks:
-                ctx.submit_device(p, n)
+            one_step()
         ctx.sync(); ctx.reset(); ctx.reset_timing()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            for (p, n, _g) in ds.blocks:
-                ctx.submit_device(p, n)
+            one_step()
         ctx.sync()
         el = time.perf_counter() - t0
         tm = ctx.timing()
@@ -143,7 +169,9 @@ def resident_leg(m, local, mode, sam, pairs, block_groups, read_len, steps, warm
         algo = (ds.total_bytes + out_b) * steps
         ach = algo / (tm.tile_kernel_ms / 1e3) / 1e9 if tm.tile_kernel_ms > 0 else 0.0
         return {"value": ds.total_groups * steps / el, "unit": "read-pairs/s", "ms_per_step": el / steps * 1e3, "pairs": ds.total_groups,
-                "workload": f"{ds.total_groups} synthetic pairs, {mode} mode, sam={'yes' if sam else 'no'}, {ds.total_bytes / 1e9:.1f} GB resident",
+                "workload": f"{what}{ds.total_groups} synthetic {read_len} bp pairs, {'mm10' if genome else 'hg38'} names, {lanes} lane(s), {mode} mode, "
+                            f"sam={'yes' if sam else 'no'}, {ds.total_bytes / 1e9:.1f} GB resident" + (", every step with duplicate marking + chromosome-pair counts" if dedup else ""),
+                **extra,
                 "bytes_per_pair_in": ds.total_bytes / ds.total_groups, "bytes_per_pair_out": out_b / ds.total_groups,
                 "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                              "avg_launch_ms": tm.tile_kernel_ms / tm.tile_launches if tm.tile_launches else None,
@@ -153,15 +181,25 @@ def resident_leg(m, local, mode, sam, pairs, block_groups, read_len, steps, warm
         ctx.close()
 
 
+# BASELINE.json configs[1..4]: what one GPU holds.  (configs[0] is the reference's own CPU plumbing case: a parity-test size, no bench line.)
+PRESETS = {
+    "C2": dict(pairs=100_000_000, read_len=150, genome=0, lanes=1, what="C2: 100 M 150 bp PE Micro-C read pairs, hg38, one MI355X"),
+    "C3": dict(pairs=125_000_000, read_len=150, genome=0, lanes=1, what="C3: 1 B 150 bp PE Hi-C read pairs, hg38, sharded across 8 MI355X (125 M per GPU), cross-shard duplicate marking"),
+    "C4": dict(pairs=100_000_000, read_len=100, genome=0, lanes=1, what="C4: unstitched mode, split-read chimeric alignments, 2 x 100 bp PE, hg38, one MI355X (100 M pairs)"),
+    "C5": dict(pairs=100_000_000, read_len=100, genome=1, lanes=4, what="C5: mm10 100 bp PE Hi-C, 4 MI355X (100 M pairs per GPU), 4 lanes, inter-lane duplicates kept (-b)"),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=int(os.environ.get("MKT_BENCH_PAIRS", 100_000_000)), help="read pairs per GPU")
+    ap.add_argument("--config", default="C2", choices=sorted(PRESETS), help="BASELINE.json config: pairs per GPU, read length, genome names, lanes (-b)")
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (default: the config's; MKT_BENCH_PAIRS overrides)")
     ap.add_argument("--block-groups", type=int, default=1 << 21, help="read groups per block (one kernel pass); 2^21 groups = 1.9 GB of SAM text")
     ap.add_argument("--sam", default="no", choices=["no", "yes"])
-    ap.add_argument("--read-len", type=int, default=150, help="read length of the synthetic data (BASELINE config: 150)")
+    ap.add_argument("--read-len", type=int, default=None, help="read length of the synthetic data (default: the config's)")
     ap.add_argument("--tiles", default="auto", choices=["fast", "auto"], help="tile geometry: chosen per input after a probe block (the library default), or the 48 KiB lean tiles forced")
     ap.add_argument("--mode", default="unc", choices=["unc", "flash"])
     ap.add_argument("--dedup", default="yes", choices=["yes", "no"],
@@ -169,11 +207,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the sam=yes and flash resident legs")
     ap.add_argument("--leg-pairs", type=int, default=32_000_000, help="read pairs of the sam=yes / flash legs")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=16_000_000, help="pairs of the file the CPU reference and the end-to-end executables are timed on (~20 s of reference time)")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=12_000_000, help="pairs of the file the CPU reference and the end-to-end executables are timed on (~16 s of reference time per run)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI)")
     ap.add_argument("--same-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal only: run the N > 1 code path (process group, RCCL all_to_all of the key space) with whatever WORLD_SIZE is, even 1")
     args = ap.parse_args()
+    preset = PRESETS[args.config]
+    if args.pairs is None:
+        args.pairs = int(os.environ.get("MKT_BENCH_PAIRS", preset["pairs"]))
+    if args.read_len is None:
+        args.read_len = preset["read_len"]
+    genome, lanes = preset["genome"], preset["lanes"]
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -210,12 +254,13 @@ def main():
     tdev = "cuda" if (dist is None or args.backend == "nccl") else "cpu"
 
     profile = 0 if args.mode == "unc" else 1
-    seed = 20260104 + 1  # seeds 20260104 + config index
+    seed = 20260104 + int(args.config[1]) - 1  # seeds 20260104 + config index (BASELINE.json configs[1] = C2)
     tiles = m.TILES_FAST if args.tiles == "fast" else m.TILES_AUTO
     dedup = args.dedup == "yes"
-    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=tiles, extensions=m.EXT_KEYS if dedup else 0)
+    ext = (m.EXT_KEYS | (m.EXT_LANES if lanes > 1 else 0)) if dedup else 0      # lanes > 1: the lane joins the duplicate key (the driver's -b)
+    ctx = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=tiles, extensions=ext)
     t0 = time.time()
-    ds = ctx.dataset(seed, profile, args.pairs, args.block_groups, first_group=rank * args.pairs, genome=0, read_len=args.read_len, lanes=1,
+    ds = ctx.dataset(seed, profile, args.pairs, args.block_groups, first_group=rank * args.pairs, genome=genome, read_len=args.read_len, lanes=lanes,
                      tail_group=(rank == world - 1))
     log(f"[rank {rank}] data set: {ds.total_groups} pairs, {ds.total_bytes / 1e9:.2f} GB in {ds.n_blocks} blocks, generated in {time.time() - t0:.1f} s")
     drop_last = rank == world - 1          # every rank holds pairs; the input's end is on the last one (quirk Q1)
@@ -271,7 +316,7 @@ def main():
     # the same passes without the extensions (exactly the reference's behaviour and outputs), on a second context
     plain = None
     if dedup:
-        ctx2 = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=tiles)
+        ctx2 = m.Context(args.mode, 0.5, 10, args.sam == "yes", 8, device=local, tiles=tiles)      # (no extensions)
         el2, tmg2 = timed(ctx2, False)
         plain = (el2, tmg2.tile_kernel_ms, tmg2.tile_launches)
         ctx2.close()
@@ -313,7 +358,7 @@ def main():
         try:
             import glob
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if cands and tm_launch and args.read_len == 150 and args.sam == "no" and args.mode == "unc":
+            if cands and tm_launch and args.config == "C2" and args.read_len == 150 and args.sam == "no" and args.mode == "unc":
                 tj = json.loads(open(cands[-1]).read())
                 if tj.get("block_groups") == args.block_groups and ("duplicate marking" in tj.get("workload", "")) == dedup:
                     traffic = tj["traffic_over_algorithmic"] * algo_bytes_step * args.steps / tm_launch
@@ -324,7 +369,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu, e2e = cpu_baseline(ctx, ds, args.cpu_sample_pairs, 8, args.mode)
         result = {
-            "metric": ("read-pairs/sec through sam2pairs+dedup" if dedup else "read-pairs/sec through sam2pairs") + " (150 bp PE, hg38 names, SAM text resident in HBM)",
+            "metric": ("read-pairs/sec through sam2pairs+dedup" if dedup else "read-pairs/sec through sam2pairs")
+                      + f" ({args.read_len} bp PE, {'mm10' if genome else 'hg38'} names, SAM text resident in HBM)",
             "value": value,
             "unit": "read-pairs/s",
             "n_gpus": world,
@@ -337,9 +383,10 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: {args.pairs} synthetic {args.read_len} bp PE read pairs per GPU, hg38 chromosome names, {args.mode} mode, sam={args.sam}, "
-                            f"seed {seed}, one step = one pass over the whole resident data set"
+                "workload": f"{preset['what']} -- {args.pairs} synthetic {args.read_len} bp PE read pairs per GPU, {'mm10' if genome else 'hg38'} chromosome names, "
+                            f"{lanes} lane(s), {args.mode} mode, sam={args.sam}, seed {seed}, one step = one pass over the whole resident data set"
                             + (" + duplicate marking of the reported pairs on (chr1,pos1,chr2,pos2,strands) + per-chromosome-pair counts" if dedup else ""),
+                "preset": args.config,
                 "pairs_per_gpu": ds.total_groups,
                 "sam_bytes_per_gpu": ds.total_bytes,
                 "bytes_per_pair_in": ds.total_bytes / ds.total_groups,
@@ -393,10 +440,16 @@ def main():
         try:
             if args.sam == "no":
                 result["sam_yes"] = resident_leg(m, local, args.mode, True, min(args.pairs, args.leg_pairs), args.block_groups, args.read_len, legs_steps,
-                                                 1, seed, tiles, barrier)
+                                                 1, seed, tiles, barrier, genome=genome, lanes=lanes)
             if args.mode == "unc":
                 result["flash"] = resident_leg(m, local, "flash", args.sam == "yes", min(args.pairs, args.leg_pairs), args.block_groups // 2, args.read_len,
-                                               legs_steps, 1, seed + 1, tiles, barrier)
+                                               legs_steps, 1, seed + 100, tiles, barrier, genome=genome, lanes=lanes)
+            if args.config == "C2" and args.mode == "unc" and args.sam == "no":
+                # the single-GPU share of BASELINE.json configs[3] and [4], same seeds as `--config C4` / `--config C5`
+                result["c4_unc100"] = resident_leg(m, local, "unc", False, min(args.pairs, args.leg_pairs), args.block_groups, PRESETS["C4"]["read_len"], legs_steps,
+                                                   1, 20260104 + 3, tiles, barrier, genome=0, lanes=1, dedup=dedup, what="C4 shape: ")
+                result["c5_mm10_4lanes"] = resident_leg(m, local, "unc", False, min(args.pairs, args.leg_pairs), args.block_groups, PRESETS["C5"]["read_len"], legs_steps,
+                                                        1, 20260104 + 4, tiles, barrier, genome=1, lanes=4, dedup=dedup, what="C5 shape (one GPU's share): ")
         except Exception as ex:      # an auxiliary leg never takes the headline down with it
             result["extra_legs_error"] = repr(ex)
     if dist is not None:

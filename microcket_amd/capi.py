@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_FLASH, MODE_UNC = 0, 1
-TILES_AUTO, TILES_FAST, TILES_SMALL = 0, 1, 2
+TILES_AUTO, TILES_FAST, TILES_SMALL, TILES_WAVE = 0, 1, 2, 3
 EXT_KEYS = 1
 EXT_LANES = 2
 KEY_BYTES = 24
@@ -265,6 +265,23 @@ class Context:
         sb = C.create_string_buffer(max(ns_.value, 1))
         self._chk(self.L.mkt_fetch_last_block(self.h, pb, np_.value, C.byref(np_), sb, ns_.value, C.byref(ns_)), "mkt_fetch_last_block")
         return pb.raw[:np_.value], sb.raw[:ns_.value]
+
+    def fetch_last_block_np(self):
+        """the same as numpy uint8 arrays (no extra copies: the blocks of the bench are 100 MB of .pairs)"""
+        import numpy as np
+        np_, ns_ = C.c_size_t(), C.c_size_t()
+        self._chk(self.L.mkt_fetch_last_block(self.h, None, 0, C.byref(np_), None, 0, C.byref(ns_)), "mkt_fetch_last_block")
+        pb = np.empty(max(np_.value, 1), dtype=np.uint8)
+        sb = np.empty(max(ns_.value, 1), dtype=np.uint8)
+        self._chk(self.L.mkt_fetch_last_block(self.h, pb.ctypes.data_as(C.c_void_p), np_.value, C.byref(np_), sb.ctypes.data_as(C.c_void_p), ns_.value, C.byref(ns_)),
+                  "mkt_fetch_last_block")
+        return pb[:np_.value], sb[:ns_.value]
+
+    def copy_to_host_np(self, d_ptr, n):
+        import numpy as np
+        buf = np.empty(max(n, 1), dtype=np.uint8)
+        self._chk(self.L.mkt_copy_to_host(self.h, C.c_void_p(d_ptr), buf.ctypes.data_as(C.c_void_p), n), "mkt_copy_to_host")
+        return buf[:n]
 
     def copy_to_host(self, d_ptr, n):
         buf = C.create_string_buffer(max(n, 1))

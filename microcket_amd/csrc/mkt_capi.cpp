@@ -193,7 +193,7 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
     mkt_ctx* c = new mkt_ctx();
     c->p = *p;
     c->P.mode = p->mode; c->P.ratio = p->min_mapped_ratio; c->P.min_mapq = (uint32_t)p->min_mapq; c->P.write_sam = p->write_sam ? 1 : 0;
-    c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;
+    c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : (p->tiles == MKT_TILES_WAVE ? CFG_WAVE : CFG_FAST);
     { const char* e = getenv("MKT_NO_LEAN"); c->no_lean = e && e[0] == '1'; }
     size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)64 << 20);
     if (bc < 4096) bc = 4096;
@@ -378,10 +378,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
         HIPCHK(c, hipEventCreate(&e1));
         c->ev.push_back(e0); c->ev.push_back(e1); c->ev_bytes.push_back(n);
     }
-#ifndef MKT_WPS
-#define MKT_WPS 4              // workgroups of the lean kernel per CU (mkt_kernels.hip compiles it for that many waves per SIMD)
-#endif
-    const uint32_t max_wgs = 256u * (uint32_t)MKT_WPS;      // 256 CUs: every workgroup resident, tiles dealt statically
+    const uint32_t max_wgs = fast_max_workgroups(cfg);       // every workgroup resident, tiles dealt statically
     int grid = (int)(ntiles < max_wgs ? ntiles : max_wgs);
     const bool lean = !c->p.ordered && cfg != CFG_SMALL && !c->no_lean;
     HIPCHK(c, hipEventRecord(e0, c->stream));

@@ -379,23 +379,6 @@ MKT_HD int text_cmp(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, u
 template <bool WIN = false>
 MKT_HD bool text_eq(const TextView& tv, uint32_t a, uint32_t alen, uint32_t b, uint32_t blen) {
     if (alen != blen) return false;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(MKT_EQ_BATCH)
-    if (WIN && alen <= 48u) {
-        // names of up to 48 bytes: every dword pair is loaded first and compared afterwards -- one LDS round trip instead of
-        // one per dword (a wave runs the longest lane's trip count anyway: some lane always holds an equal pair)
-        const uint32_t ra = a - tv.w0, rb = b - tv.w0;
-        uint32_t acc = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < 12u; ++k) {
-            if (4u * k < alen) {
-                uint32_t x = win_load4(tv, ra + 4u * k) ^ win_load4(tv, rb + 4u * k);
-                if (alen - 4u * k < 4u) x &= (1u << ((alen - 4u * k) * 8u)) - 1u;
-                acc |= x;
-            }
-        }
-        return acc == 0u;
-    }
-#endif
     if (WIN || (tv.inside(a, alen) && tv.inside(b, blen))) {
         // last dword first: read names of one run share their head and differ in the trailing coordinates
         const uint32_t ra = a - tv.w0, rb = b - tv.w0;

@@ -28,23 +28,17 @@ namespace mkt {
 constexpr int kLeanTile = 49152, kLeanHB = 3072, kLeanHF = 3072, kLeanLCAP = 168;
 constexpr int kMidTile = 32768, kMidHB = 2048, kMidHF = 3072, kMidLCAP = 160;
 constexpr int kDenseTile = 16384, kDenseHB = 1024, kDenseHF = 2048, kDenseLCAP = 160;
+constexpr int kWaveTile = 16384, kWaveHB = 2048, kWaveHF = 3072, kWaveLCAP = 64, kWaveGCAP = 40;      // one wave per tile
 
-template <int TILE_, int HB_, int HF_, int LCAP_>
+template <int TILE_, int HB_, int HF_, int LCAP_, int GCAP_ = 96>
 struct FastCfg {
     static constexpr int TILE = TILE_, HB = HB_, HF = HF_, W = HB_ + TILE_ + HF_, LCAP = LCAP_;
     static constexpr int MW = (W + 63) / 64 + 3;
-#ifndef MKT_GCAP
-#define MKT_GCAP 96
-#endif
-    static constexpr int GCAP = MKT_GCAP;            // emitting groups per tile (more: generic kernel)
+    static constexpr int GCAP = GCAP_;               // emitting groups per tile (more: generic kernel)
     static constexpr int NV16 = (W + 15) / 16;       // 16-byte vectors of the window
     static constexpr int HMW = (NV16 + 63) / 64;     // 64-bit words of the "vector holds a newline" bitmap
     static constexpr int HCH = 8, HEADB = HCH * 16;  // head store: 16-byte chunks / bytes per line
-#if defined(MKT_HSTRIDE8)
-    static constexpr int HSTRIDE = HEADB + 8;        // row pitch 34 dwords: rows 8-byte aligned (two 64-bit stores per head chunk instead of four dwords)
-#else
     static constexpr int HSTRIDE = HEADB + 4;        // row pitch: 33 dwords, so lanes reading the same column of their own rows hit 32 different banks
-#endif
     static constexpr int HW = LCAP_ * HSTRIDE;       // bytes of the head store
     static_assert(TILE_ % 16 == 0 && HB_ % 16 == 0 && HF_ % 16 == 0, "16-byte vector staging");
     static_assert(W < 65536, "window-relative offsets are 16 bit");
@@ -90,9 +84,6 @@ struct FastState {
     } u;
     // one bit per line of the window (ballots of the parse / start phases)
     uint64_t m_surv[4], m_eqp[4], m_r1[4], m_r2[4], m_start[4], m_emit[4];
-    // the tile's own group starts in line order: wave w of the start phase fills start_list[64 w, 64 w + start_cnt[w])
-    uint8_t start_list[256];
-    uint32_t start_cnt[4];
     // extension: this workgroup's cache of the chromosome table, kept across its tiles.  One word per entry (name bytes
     // in bits 0..47, table slot in 48..60, valid in 63), so that a lane never pairs one entry's name with another's slot
     uint64_t cc[64];
@@ -149,13 +140,7 @@ template <class Cfg> MKT_HD uint32_t fast_line_end(const FastState<Cfg>& st, con
     return i + 1 < st.NL ? G.w0 + st.goff[i + 1] - 1u : st.last_line_end;
 }
 
-// whitespace bits (bit b <-> byte b) of the 16 window bytes starting at window offset r0 (multiple of 16)
-MKT_HD uint32_t ws_bits16_ref(const uint8_t* win, uint32_t r0, uint32_t wlen) {
-    uint32_t m = 0;
-    for (uint32_t b = 0; b < 16u; ++b) if (r0 + b < wlen && is_ws(win[r0 + b])) m |= 1u << b;
-    return m;
-}
-// the two 64-bit whitespace words of line i's head (bit k <-> byte k of the line), from its head-mask row
+// the two 64-bit SEPARATOR words of line i's head (bit k <-> byte k of the line is <= 0x20), from its head-mask row
 template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t i, uint64_t& ws0, uint64_t& ws1) {
     const uint64_t* row = reinterpret_cast<const uint64_t*>(st.u.m.hmask[i]);
     const uint64_t A = row[0], B = row[1];
@@ -163,7 +148,8 @@ template <class Cfg> MKT_HD void fast_head_ws(const FastState<Cfg>& st, uint32_t
     ws0 = sh ? ((A >> sh) | (B << (64u - sh))) : A;
     ws1 = B >> sh;
 }
-// one head chunk: the 16 text bytes at window offset r0 (multiple of 16); bytes at or past the block end read as 0
+// one head chunk: the 16 text bytes at window offset r0 (multiple of 16); bytes at or past the block end read as 0 and are
+// no separators.  Separator bits: byte <= 0x20 (tab, newline, the other whitespace and control bytes)
 template <class Cfg> MKT_HD void fast_head_chunk_ref(FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G, uint32_t i, uint32_t c) {
     const uint32_t r0 = 16u * ((uint32_t)st.hv16[i] + c);
     uint32_t m = 0;
@@ -171,7 +157,7 @@ template <class Cfg> MKT_HD void fast_head_chunk_ref(FastState<Cfg>& st, const u
         const uint64_t g = (uint64_t)G.w0 + r0 + b;
         const uint8_t ch = g < n ? text[g] : 0;
         st.win[i * Cfg::HSTRIDE + 16u * c + b] = ch;
-        if (g < n && is_ws(ch)) m |= 1u << b;
+        if (g < n && ch <= 0x20u) m |= 1u << b;
     }
     st.u.m.hmask[i][c] = (uint16_t)m;
 }
@@ -197,25 +183,161 @@ template <class Cfg> MKT_HD uint32_t fast_row_start(const FastState<Cfg>& st, co
     const uint32_t p = f0 ? a0 : (f1 ? a1 : (f2 ? a2 : a3));       // first newline of the vector (16: none -- cannot happen)
     return p + 1u;
 }
-// distance from the start of line i to its newline when that lies inside the head (else any value >= 128): the next table
-// entry names the vector, the exact byte comes from this line's own row
-template <class Cfg> MKT_HD uint32_t fast_line_len_in_head(const FastState<Cfg>& st, uint32_t i, uint32_t goff) {
-    const uint32_t hv = st.hv16[i], hvn = st.hv16[i + 1u];
-    if (hvn * 16u >= goff + 128u || hvn >= hv + (uint32_t)Cfg::HCH) return 0xFFFFu;
-    const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + 16u * (hvn - hv)]);
-    for (uint32_t d = 0; d < 4u; ++d) {
-        uint32_t f = nl_flags_exact(row[d]);
-        // the line's own leading newline sits in this very vector when hvn == hv: skip what lies in front of the line
-        while (f) {
-            const uint32_t pos = hvn * 16u + 4u * d + (ctz32(f) >> 3);
-            if (pos >= goff) return pos - goff;
-            f &= f - 1u;
-        }
+// ---- parse line i ------------------------------------------------------------------------------
+// Straight-line record parser of the lean path (every lane of a wave runs the same few hundred instructions; the generic
+// parsers of mkt_core.h loop per byte / per token with trip counts that differ from lane to lane).
+//
+// A line is LEAN when, up to the end of its sixth token: its first byte is no separator (byte <= 0x20), every token is
+// followed by exactly one tab and a token byte, and the sixth token ends at a tab, at the line's newline or at the end of the
+// block.  The six tokens are then exactly what `ss >> a >> b ...` (pairutil.h:152-161) extracts: the only bytes <= 0x20 the
+// reference meets on its way are those tabs.  Everything else is LP_ODD / LP_LONG: the tile goes to the generic kernel.
+enum { LP_OK = 1, LP_NOREC = 2, LP_LONG = 0, LP_ODD = -1 };
+
+// four ASCII digits, text order = byte order (byte 0 the most significant digit) -> value; ok cleared when a byte is no digit
+MKT_HD uint32_t dec4(uint32_t w, bool& ok) {
+    const uint32_t d = w ^ 0x30303030u;
+    if (((d + 0x76767676u) | d) & 0x80808080u) ok = false;                     // some byte > 9
+    const uint32_t x = (d << 3) + (d << 1) + (d >> 8);                          // byte 0: 10 b0 + b1, byte 2: 10 b2 + b3 (no carries: <= 99)
+    return mul24(x & 0xFFu, 100u) + ((x >> 16) & 0xFFu);
+}
+// unsigned decimal token of 1..4 bytes starting at head-store offset a
+MKT_HD uint32_t lean_uint4(const TextView& tv, uint32_t a, uint32_t len, bool& ok) {
+    const uint32_t sh = 8u * (4u - len);                                        // 0, 8, 16, 24
+    const uint32_t w = (win_load4(tv, a) << sh) | (0x30303030u & ((1u << sh) - 1u));      // right aligned, '0' in front
+    return dec4(w, ok);
+}
+// unsigned decimal token of 1..10 bytes ENDING at head-store offset e (exclusive); the 12 bytes in front of e are readable
+MKT_HD uint32_t lean_uint12(const TextView& tv, uint32_t e, uint32_t len, bool& ok) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tv.win);
+    const uint32_t a = e - 12u, k = a >> 2, sh = a & 3u;
+    const uint32_t q0 = w[k], q1 = w[k + 1], q2 = w[k + 2], q3 = w[k + 3];
+    uint32_t x0, x1, x2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    x0 = __builtin_amdgcn_alignbyte(q1, q0, sh); x1 = __builtin_amdgcn_alignbyte(q2, q1, sh); x2 = __builtin_amdgcn_alignbyte(q3, q2, sh);
+#else
+    x0 = sh ? ((q0 >> (8u * sh)) | (q1 << (32u - 8u * sh))) : q0;
+    x1 = sh ? ((q1 >> (8u * sh)) | (q2 << (32u - 8u * sh))) : q1;
+    x2 = sh ? ((q2 >> (8u * sh)) | (q3 << (32u - 8u * sh))) : q2;
+#endif
+    const uint32_t lead = 12u - len;                                            // bytes in front of the token: read as '0'
+    const uint32_t n0 = lead < 4u ? lead : 4u, n1 = lead < 4u ? 0u : (lead < 8u ? lead - 4u : 4u), n2 = lead < 8u ? 0u : lead - 8u;
+    const uint32_t m0 = n0 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n0)) - 1u), m1 = n1 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n1)) - 1u),
+                   m2 = (1u << (8u * n2)) - 1u;                                  // n2 <= 3
+    x0 = (x0 & ~m0) | (0x30303030u & m0); x1 = (x1 & ~m1) | (0x30303030u & m1); x2 = (x2 & ~m2) | (0x30303030u & m2);
+    const uint32_t A = dec4(x0, ok), B = dec4(x1, ok), C = dec4(x2, ok);
+    const uint64_t v = (uint64_t)A * 100000000ull + (uint64_t)(mul24(B, 10000u) + C);
+    if (v > 0xFFFFFFFFull) ok = false;
+    return (uint32_t)v;
+}
+// len bytes at head-store offsets a and b equal?  (eight bytes per step; reads up to 11 bytes past the ranges)
+MKT_HD bool lean_eq(const TextView& tv, uint32_t a, uint32_t b, uint32_t len) {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(tv.win);
+    const uint32_t ka = a >> 2, sa = a & 3u, kb = b >> 2, sb = b & 3u;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < len; i += 8u) {
+        const uint32_t j = i >> 2;
+        const uint32_t a0 = w[ka + j], a1 = w[ka + j + 1], a2 = w[ka + j + 2], b0 = w[kb + j], b1 = w[kb + j + 1], b2 = w[kb + j + 2];
+        uint32_t x0, x1, y0, y1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        x0 = __builtin_amdgcn_alignbyte(a1, a0, sa); x1 = __builtin_amdgcn_alignbyte(a2, a1, sa);
+        y0 = __builtin_amdgcn_alignbyte(b1, b0, sb); y1 = __builtin_amdgcn_alignbyte(b2, b1, sb);
+#else
+        x0 = sa ? ((a0 >> (8u * sa)) | (a1 << (32u - 8u * sa))) : a0; x1 = sa ? ((a1 >> (8u * sa)) | (a2 << (32u - 8u * sa))) : a1;
+        y0 = sb ? ((b0 >> (8u * sb)) | (b1 << (32u - 8u * sb))) : b0; y1 = sb ? ((b1 >> (8u * sb)) | (b2 << (32u - 8u * sb))) : b1;
+#endif
+        uint32_t d0 = x0 ^ y0, d1 = x1 ^ y1;
+        const uint32_t rem = len - i;                                           // >= 1
+        if (rem < 4u) { d0 &= (1u << (8u * rem)) - 1u; d1 = 0; }
+        else if (rem < 8u) { d1 &= (1u << (8u * (rem - 4u))) - 1u; }
+        acc |= d0 | d1;
     }
-    return 0xFFFFu;
+    return acc == 0u;
 }
 
-// ---- parse line i ------------------------------------------------------------------------------
+// Parses the record whose line starts at head-store offset `off`: sp0 / sp1 = separator bits of its bytes 0..63 / 64..127
+// (zero beyond the `room` head bytes of the line), reach = bytes from the line start to the end of the block.
+MKT_HD int parse_record_lean(const TextView& tv, uint32_t off, const Params& P, Rec& r, uint64_t sp0, uint64_t sp1, uint32_t reach) {
+    // a line without its newline at the very end of the block ends at `reach`
+    if (reach < 64u) sp0 |= 1ull << reach; else if (reach < 128u) sp1 |= 1ull << (reach - 64u);
+    uint32_t p[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 6; ++k) {                                               // the first six separators
+        if (sp0) { p[k] = ctz64(sp0); sp0 &= sp0 - 1ull; }
+        else if (sp1) { p[k] = 64u + ctz64(sp1); sp1 &= sp1 - 1ull; }
+        else p[k] = 0xFFFFu;
+    }
+    uint8_t c[6];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 6; ++k) c[k] = p[k] != 0xFFFFu ? tv.win[off + p[k]] : (uint8_t)0;
+    uint32_t prev = 0xFFFFFFFFu;                                                // separator in front of the token (-1: line start)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 6; ++k) {
+        if (p[k] == 0xFFFFu) return LP_LONG;                                    // the head ends before the sixth token does
+        const bool nl = p[k] == reach || c[k] == '\n';
+        if (p[k] == prev + 1u) return nl ? LP_NOREC : LP_ODD;                    // empty token: end of a short line, or a run of separators
+        if (nl) { if (k < 5) return LP_NOREC; break; }                         // a complete line with fewer than six tokens is no record
+        if (c[k] != '\t') return LP_ODD;
+        prev = p[k];
+    }
+    bool ok = tv.win[off] != '@';
+    r.qn_off = 0; r.qn_len = p[0];
+    r.rn_off = p[1] + 1u; r.rn_len = p[2] - p[1] - 1u;
+    const uint32_t fl_len = p[1] - p[0] - 1u, pos_len = p[3] - p[2] - 1u, mq_len = p[4] - p[3] - 1u;
+    // (12 readable bytes in front of a long field's end: true for every line whose QNAME has five bytes or more)
+    if (pos_len > 10u) { ok = false; r.pos = 0; }                               // (as parse_record: more than ten digits never fit)
+    else if (p[3] < 12u) return LP_ODD;
+    else r.pos = lean_uint12(tv, off + p[3], pos_len, ok);
+    if (fl_len <= 4u) r.flag = lean_uint4(tv, off + p[0] + 1u, fl_len, ok);
+    else if (fl_len > 10u) { ok = false; r.flag = 0; }
+    else if (p[1] < 12u) return LP_ODD;
+    else r.flag = lean_uint12(tv, off + p[1], fl_len, ok);
+    if (mq_len <= 4u) r.mapq = lean_uint4(tv, off + p[3] + 1u, mq_len, ok);
+    else if (mq_len > 10u) { ok = false; r.mapq = 0; }
+    else r.mapq = lean_uint12(tv, off + p[4], mq_len, ok);                      // (p[4] > p[3] >= 12)
+    CigarWalk cw;
+    cw.begin(r);
+    const uint32_t cs = off + p[4] + 1u, clen = p[5] - p[4] - 1u;
+    // Per OPERATION instead of per byte when the token is short and every count has at most three digits (reads below
+    // 1000 bp): bit i of `dig` <-> byte i of the token is a decimal digit; each non-digit is an operation whose count is
+    // the digit run before it, read together with the operation byte as one unaligned dword.
+    uint32_t dig = 0;
+    if (clen <= 12u) {
+        dig = digit_bits4(win_load4(tv, cs));
+        if (clen > 4u) dig |= digit_bits4(win_load4(tv, cs + 4u)) << 4;
+        if (clen > 8u) dig |= digit_bits4(win_load4(tv, cs + 8u)) << 8;
+        dig &= (1u << clen) - 1u;
+    }
+    if (clen <= 12u && !(dig & (dig >> 1) & (dig >> 2) & (dig >> 3))) {
+        uint32_t ops = ~dig & ((1u << clen) - 1u);
+        uint32_t run0 = 0;                                          // first byte of the digit run before the next operation
+        while (ops) {
+            const uint32_t q = ctz32(ops);
+            ops &= ops - 1u;
+            const uint32_t L = q - run0;                            // 0..3 digits
+            const uint32_t w = win_load4(tv, cs + q - 3u);          // bytes q-3 .. q: hundreds, tens, units, operation
+            const int32_t value = (int32_t)((L > 0u ? (w >> 16) & 15u : 0u) + (L > 1u ? mul24((w >> 8) & 15u, 10u) : 0u) + (L > 2u ? mul24(w & 15u, 100u) : 0u));
+            cw.value = value;
+            cw.op(r, (uint8_t)(w >> 24), q + 1u == clen);
+            run0 = q + 1u;
+        }
+    } else {
+        for (uint32_t i = 0; i < clen; i += 4u) {
+            uint32_t w = win_load4(tv, cs + i);
+            const uint32_t m = clen - i < 4u ? clen - i : 4u;
+            for (uint32_t b = 0; b < m; ++b) { cw.step(r, (uint8_t)(w & 0xFFu), i + b + 1u == clen); w >>= 8; }
+        }
+    }
+    cw.end(r);
+    r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;
+    return LP_OK;
+}
+
 template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& tv, const Params& P, const TileGeom& G, uint32_t i) {
     bool multi;
     const uint32_t soff = fast_row_start(st, G, i, &multi);
@@ -233,16 +355,11 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     Rec r;
     uint64_t ws0, ws1;
     fast_head_ws(st, i, ws0, ws1);
-    // the line's end: from the next table entry; the last entry ends at the block end or beyond the window
-    uint32_t L;
-    if (i + 1u < st.NL) L = fast_line_len_in_head(st, i, goff);
-    else L = st.last_line_end == kUnknown ? 0xFFFFu : st.last_line_end - gl;
-    const uint32_t room = (uint32_t)Cfg::HEADB - soff, reach = tv.n - gl;
     rec_clear(r, off);
-    const int pf = parse_record_core(tv, off, P, r, ws0, ws1, L, room < reach ? room : reach, reach);
-    if (pf != PF_OK) {
+    const int pf = parse_record_lean(tv, off, P, r, ws0, ws1, tv.n - gl);
+    if (pf == LP_LONG || pf == LP_ODD) {
         if (gl >= G.t1 && i + 1 == st.NL && G.w1 < tv.n) st.bits[i] = LB_CUT;    // last halo line: ignored (a group reaching it is deferred)
-        else { st.bits[i] = 0; st.abn = AB_LONG; }                       // fields beyond the head: generic kernel
+        else { st.bits[i] = 0; st.abn = pf == LP_LONG ? AB_LONG : AB_TAB; }      // fields beyond the head / an odd shape: generic kernel
         return;
     }
     st.rc.f.pos[i] = r.pos; st.rc.f.lclip[i] = (uint32_t)r.lclip; st.rc.f.rclip[i] = (uint32_t)r.rclip; st.rc.f.mappable[i] = (uint32_t)r.mappable;
@@ -251,17 +368,16 @@ template <class Cfg> MKT_HD void fast_parse(FastState<Cfg>& st, const TextView& 
     st.qn_off[i] = (uint8_t)r.qn_off; st.qn_len[i] = (uint8_t)r.qn_len; st.rn_off[i] = (uint8_t)r.rn_off; st.rn_len[i] = (uint8_t)r.rn_len;
     st.segCnt[i] = (uint8_t)(r.segCnt > 4 ? 4 : r.segCnt);
     uint8_t b = r.survive ? LB_SURVIVE : 0;
-    // the emitter copies QNAME / RNAME together with the separator that follows them: it must be a tab
-    if (tv.win[off + r.qn_off + r.qn_len] != '\t' || tv.win[off + r.rn_off + r.rn_len] != '\t') st.abn = AB_TAB;
-    if (i > 0) {
-        // same QNAME token as the line before: its first token must start at its first byte
+    if (i > 0 && pf == LP_OK) {
+        // same QNAME token as the line before: its first r.qn_len bytes and the tab behind them (its own lane sets off16[i - 1]
+        // in this same phase: recompute).  A line before that is no lean record only ever costs the direct comparison in
+        // fast_is_start (or defers the tile by itself).
         bool pm;
-        const uint32_t psoff = fast_row_start(st, G, i - 1u, &pm);        // (its own lane sets off16[i - 1] in this same phase: recompute)
+        const uint32_t psoff = fast_row_start(st, G, i - 1u, &pm);
         const uint32_t poff = mul24(i - 1u, (uint32_t)Cfg::HSTRIDE) + psoff;
         const uint32_t ql = r.qn_len;
-        if (is_ws(tv.win[poff])) st.abn = AB_PREV_WS;
-        else if (ql + 1u > (uint32_t)Cfg::HEADB - psoff) st.abn = AB_PREV_HEAD;          // beyond the previous line's head
-        else if (text_eq<true>(tv, off + r.qn_off, ql, poff, ql) && is_ws(tv.win[poff + ql])) b |= LB_EQPREV;
+        if (ql + 1u > (uint32_t)Cfg::HEADB - psoff || ql > 100u) st.abn = AB_PREV_HEAD;      // beyond the previous line's head (lean_eq reads 11 bytes past the names)
+        else if (lean_eq(tv, off, poff, ql + 1u)) b |= LB_EQPREV;
     }
     st.bits[i] = b;
 }
@@ -541,50 +657,6 @@ template <class Cfg> MKT_HD void fast_emit_line(const FastState<Cfg>& st, uint32
         for (uint32_t k = 0; k < rl[r]; k += 4u) {
             uint32_t x = state_load4(base, rs[r] + k);
             const uint32_t take = rl[r] - k < 4u ? rl[r] - k : 4u;
-            if (take < 4u) x &= (1u << (8u * take)) - 1u;
-            acc |= (uint64_t)x << (8u * cnt);
-            cnt += take;
-            if (cnt >= 4u) {
-                const uint32_t v = (uint32_t)acc;
-                if (first) { uint8_t* b = reinterpret_cast<uint8_t*>(d); for (uint32_t q = a; q < 4u; ++q) *MKT_GLOBAL(uint8_t, b + q) = (uint8_t)(v >> (8u * q)); first = false; }
-                else *MKT_GLOBAL(uint32_t, d) = v;
-                ++d; acc >>= 32; cnt -= 4u;
-            }
-        }
-    }
-    {   // what is left: cnt (< 4) bytes of the last, shared dword
-        uint8_t* b = reinterpret_cast<uint8_t*>(d);
-        for (uint32_t q = first ? a : 0u; q < cnt; ++q) *MKT_GLOBAL(uint8_t, b + q) = (uint8_t)((uint32_t)acc >> (8u * q));
-    }
-}
-
-// The same for bytes [lo, hi) of the line only: several lanes share one line (the emit phase is a serial byte stream per lane,
-// its length is the phase's critical path).  Every part starts and ends with single bytes like a whole line does.
-template <class Cfg> MKT_HD void fast_emit_part(const FastState<Cfg>& st, uint32_t slot, uint32_t plen, uint8_t* line_dst, uint32_t lo, uint32_t hi) {
-    if (lo >= hi) return;
-    const auto& g = st.u.g;
-    const uint8_t* base = reinterpret_cast<const uint8_t*>(&st);
-    const uint32_t w = (uint32_t)(st.win - base);
-    const uint32_t e0 = g.l_e0[slot], e1 = g.l_e1[slot], e2 = g.l_e2[slot], e3 = g.l_e3[slot];
-    const uint32_t rs[5] = {w + g.l_qa[slot], w + g.l_ca[slot], (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litA[slot][0]) - base),
-                            w + g.l_cb[slot], (uint32_t)(reinterpret_cast<const uint8_t*>(&g.l_litB[slot][0]) - base)};
-    const uint32_t rb[6] = {0u, e0, e1, e2, e3, plen};            // run r is line bytes [rb[r], rb[r + 1])
-    uint8_t* dst = line_dst + lo;
-    const uint32_t a = (uint32_t)((uintptr_t)dst & 3u);
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst - a);            // the aligned dword that holds the part's first byte
-    uint64_t acc = 0;
-    uint32_t cnt = a;                                              // its low `a` bytes belong to whoever writes in front
-    bool first = a != 0u;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int r = 0; r < 5; ++r) {
-        const uint32_t b0 = rb[r] > lo ? rb[r] : lo, b1 = rb[r + 1] < hi ? rb[r + 1] : hi;
-        if (b0 >= b1) continue;
-        const uint32_t src = rs[r] + (b0 - rb[r]), len = b1 - b0;
-        for (uint32_t k = 0; k < len; k += 4u) {
-            uint32_t x = state_load4(base, src + k);
-            const uint32_t take = len - k < 4u ? len - k : 4u;
             if (take < 4u) x &= (1u << (8u * take)) - 1u;
             acc |= (uint64_t)x << (8u * cnt);
             cnt += take;

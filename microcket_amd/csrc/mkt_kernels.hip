@@ -14,20 +14,6 @@
 #include <type_traits>
 #include "mkt_launch.h"
 
-// tile geometry of the fast configuration (the lean and the generic kernel must agree on TILE)
-#ifndef MKT_RR
-#define MKT_RR 2          // waves that share the group phase of a tile (lines dealt round-robin; 2 beats 1, 3 and 4 at 48 KiB tiles)
-#endif
-#ifndef MKT_LEAN_TILE      // experiments override the geometry of mkt_fast.h
-#define MKT_LEAN_TILE kLeanTile
-#define MKT_LEAN_HB kLeanHB
-#define MKT_LEAN_HF kLeanHF
-#define MKT_LEAN_LCAP kLeanLCAP
-#endif
-#ifndef MKT_LOAD_BATCH
-#define MKT_LOAD_BATCH 14     // (every window vector of a lane in flight at once: 14 x 16 bytes; 7 measured 0.7 % slower)
-#endif
-
 namespace mkt {
 
 constexpr int NT = 256;                      // 4 waves per workgroup
@@ -100,8 +86,8 @@ __device__ inline uint32_t wave_iscan32(uint32_t v) {
     return v;
 }
 // exclusive scan of three u32 per thread over the workgroup (the tile sums of k_fast: every total stays far below 2^32)
-// (tail_barrier = false: the caller reaches a barrier of its own before the scratch is used again)
-template <bool tail_barrier = true>
+// (no barrier at the end: the caller reaches one of its own before the scratch is used again)
+template <int NW>
 __device__ inline void block_exscan3(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& ta, uint32_t& tb, uint32_t& tc, ScanScratch& sc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t ia = wave_iscan32(a), ib = wave_iscan32(b), ic = wave_iscan32(c);
@@ -110,14 +96,13 @@ __device__ inline void block_exscan3(uint32_t& a, uint32_t& b, uint32_t& c, uint
     uint32_t pa = 0, pb = 0, pc = 0;
     ta = 0; tb = 0; tc = 0;
 #pragma unroll
-    for (int w = 0; w < NT / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
         const uint64_t x = sc.a[w];
         const uint32_t xa = (uint32_t)x, xb = (uint32_t)(x >> 32), xc = (uint32_t)sc.b[w];
         if (w < wv) { pa += xa; pb += xb; pc += xc; }
         ta += xa; tb += xb; tc += xc;
     }
     a = pa + ia - a; b = pb + ib - b; c = pc + ic - c;
-    if (tail_barrier) __syncthreads();
 }
 
 // exclusive scan of two u64 lanes-values over the workgroup; totals returned to every thread
@@ -166,11 +151,9 @@ __device__ inline uint32_t has_nl(uint32_t x) {
     const uint32_t t = x ^ 0x0A0A0A0Au;
     return (t - 0x01010101u) & ~t & 0x80808080u;
 }
-__device__ inline uint32_t ws_flags(uint32_t x) {                 // byte in {9..13, 32}
+__device__ inline uint32_t sep_flags(uint32_t x) {                // byte <= 0x20: tab, newline, the other whitespace and control bytes
     const uint32_t y = x & 0x7F7F7F7Fu;
-    const uint32_t ctl = (y + 0x77777777u) & ~(y + 0x72727272u);  // >= 9 and not >= 14
-    const uint32_t sp = ~((y ^ 0x20202020u) + 0x7F7F7F7Fu);       // == 32
-    return (ctl | sp) & ~x & 0x80808080u;
+    return ~((y + 0x5F5F5F5Fu) | x) & 0x80808080u;               // bit 7 of (y + 0x5F) <=> y >= 0x21
 }
 // sixteen 0x80 byte flags (four dwords) -> one bit per byte.  v_dot4_u32_u8 does the gathering: the flags are 128 x {0, 1}, the
 // weights 1, 2, 4, 8 (16 .. 128 for the second dword), so two dot products per byte of result and one shift (the multiply-
@@ -448,17 +431,18 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 // ---------------------------------------------------------------------------------------------
 // k_fast: the lean tile kernel (mkt_fast.h).  Same phases as k_tiles without any generic path; a
 // tile that needs one is appended to the defer list and produces nothing here.
-typedef FastCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, MKT_LEAN_LCAP> CfgLean;
+// NTW threads per workgroup; RR waves share the group phase of a tile (lines dealt round-robin: 2 beats 1, 3 and 4 at
+// 48 KiB tiles); WPS = waves per SIMD the kernel is compiled for (profiles/r02_kernel_variants.txt has the measurements
+// behind these choices and behind the variants that are gone from the source).
+constexpr int kLoadBatch = 14;     // 16-byte window vectors of a lane in flight at once
 
-#ifndef MKT_WPS
-#define MKT_WPS 4          // waves per SIMD the lean kernel is compiled for (workgroups of 4 waves per CU)
-#endif
-template <class Cfg>
-__global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves per SIMD: four 36 KB workgroups per CU
+template <class Cfg, int NTW, int RR, int WPS>
+__global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
     __shared__ FastState<Cfg> st;
     __shared__ ScanScratch scan;
     constexpr int NVEC = (Cfg::W + 15) / 16;
-    static_assert(Cfg::LCAP <= NT, "one line per thread in the sums");
+    static_assert(Cfg::LCAP <= NTW, "one line per thread in the sums");
+    static_assert(NTW % 64 == 0 && NTW <= NT && RR * 64 <= NTW, "whole waves");
     const int tid0 = threadIdx.x;
     const Params P = a.P;
     const uint32_t n = a.n;
@@ -470,57 +454,12 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
     if (tid0 < (int)C_COUNT) wg_cnt[tid0] = 0;
     fast_init(st, (uint32_t)tid0);
     // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
-#if defined(MKT_STAGGER_SHIFT)
-    // Workgroups of one launch all start in the same phase and, tile after tile of equal work, stay there: everybody scans
-    // (HBM-bound), then everybody computes.  A one-off delay of part of the workgroups puts them out of phase, so that the scan
-    // of one half meets the compute phases of the other for the rest of the launch.
-    {
-        const uint32_t ph = (blockIdx.x >> MKT_STAGGER_SHIFT) & (uint32_t)(MKT_STAGGER_PHASES - 1);
-        for (uint32_t k = 0; k < ph * (uint32_t)MKT_STAGGER_SLEEPS; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#ifndef MKT_PREFETCH
-#define MKT_PREFETCH 0       // 16-byte vectors per lane of the NEXT tile's window that are loaded before the current tile's emit phase
-#endif
-    constexpr int PF = MKT_PREFETCH;
-    uint4 xp[PF > 0 ? PF : 1];
-    auto prefetch = [&](uint32_t tt) {       // issue the loads only: they complete behind the latency-bound tail of the current tile
-        const TileGeom Gp = fast_geom<Cfg>(tt, n);
-        const uint32_t nvp = (Gp.w1 - Gp.w0 + 15u) >> 4;
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const uint32_t v = (uint32_t)tid0 + (uint32_t)k * NT;
-            xp[k] = make_uint4(0, 0, 0, 0);
-            if (v < nvp) xp[k] = *reinterpret_cast<const uint4*>(a.text + Gp.w0 + (v << 4));
-        }
-    };
-    if (PF > 0 && blockIdx.x < a.ntiles) prefetch(blockIdx.x);      // (experiment switch; assumes the default tile order)
     // the output pointers once per workgroup: the per-tile limits in s_out are all rewritten by every claim (the argument block
     // lives in scratch memory by now -- five dependent loads that used to sit in front of lane 0's scan of EVERY tile)
     if (tid0 == 0) s_out = a.out;
-    uint32_t rot = 0;
-#ifndef MKT_TOUCH
-#define MKT_TOUCH 0          // 1 / 2 / 3: touch the NEXT tile's window (one dword per 128-byte line) before parse / groups / emit
-#endif
-    uint32_t touch0 = 0, touch1 = 0;
-    auto touch_next = [&](uint32_t tt) {     // pulls the next window towards this XCD's L2; nothing waits for these loads
-        if (tt >= a.ntiles) return;
-        const TileGeom Gp = fast_geom<Cfg>(tt, n);
-        const uint32_t wl = Gp.w1 - Gp.w0, o0 = (uint32_t)tid0 << 7, o1 = ((uint32_t)tid0 + NT) << 7;
-        if (o0 < wl) touch0 = *reinterpret_cast<const uint32_t*>(a.text + Gp.w0 + o0);
-        if (o1 < wl) touch1 = *reinterpret_cast<const uint32_t*>(a.text + Gp.w0 + o1);
-    };
-#if defined(MKT_XCD_MAP)
-    // Workgroups go to the 8 XCDs round-robin (blockIdx & 7), each XCD has its own L2: give the workgroups of one XCD CONSECUTIVE
-    // tiles, so that the halo a tile shares with its neighbour (6 of 54 KB) is fetched into that L2 once.
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t t_first = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-#else
-    const uint32_t t_first = blockIdx.x;
-#endif
     uint32_t gdim = gridDim.x;                                   // (read once: the dispatch packet is a scalar memory load away)
     asm volatile("" : "+s"(gdim));
-    for (uint32_t t = t_first; t < a.ntiles; t += gdim) {
+    for (uint32_t t = blockIdx.x; t < a.ntiles; t += gdim) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
         // (no barrier: the previous tile ended on one, and nothing below reads what lane 0 resets here before the barrier
@@ -535,31 +474,24 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         // ---- scan: which 16-byte vectors of the window hold a newline.  The text streams through registers only; per vector
         //      a 3-op-per-dword "some byte == '\n'" test and one ballot: 64 vectors per bitmap word, in window order.
         {
-            constexpr int LPT = (NVEC + NT - 1) / NT;          // 16-byte vectors per thread
-            constexpr int BATCH = MKT_LOAD_BATCH;
+            constexpr int LPT = (NVEC + NTW - 1) / NTW;        // 16-byte vectors per thread
+            constexpr int BATCH = LPT < kLoadBatch ? LPT : kLoadBatch;
             const uint32_t tail = (G.w1 >= n) ? (wlen & 15u) : 0u;      // bytes of a partial last vector (only the block's last window has one)
             const int wv = tid >> 6, lane = tid & 63;
 #pragma unroll
             for (int k0 = 0; k0 < LPT; k0 += BATCH) {
                 uint4 x[BATCH];
-#if defined(MKT_SETPRIO)
-                __builtin_amdgcn_s_setprio(3);                 // the loads of a window go out ahead of other waves' arithmetic
-#endif
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
-                    const uint32_t v = tid + (k0 + k) * NT;
+                    const uint32_t v = tid + (k0 + k) * NTW;
                     x[k] = make_uint4(0, 0, 0, 0);
-                    if (k0 + k < PF) { x[k] = xp[k0 + k]; continue; }      // came over during the previous tile's tail
                     // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
                     if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
                 }
-#if defined(MKT_SETPRIO)
-                __builtin_amdgcn_s_setprio(0);
-#endif
 #pragma unroll
                 for (int k = 0; k < BATCH; ++k) {              // ... then the math
                     if (k0 + k >= LPT) continue;
-                    const uint32_t v = tid + (k0 + k) * NT;
+                    const uint32_t v = tid + (k0 + k) * NTW;
                     uint4 y = x[k];
                     if (tail && v == nvec - 1u) {              // bytes past the end of the block are not text
                         uint32_t* w = reinterpret_cast<uint32_t*>(&y);
@@ -572,11 +504,10 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                     const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
                     const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
                     const uint64_t bm = __ballot((z & 0x80808080u) != 0u);
-                    if (lane == 0 && (uint32_t)((k0 + k) * (NT / 64) + wv) < (uint32_t)Cfg::HMW) st.u.m.hitmap[(k0 + k) * (NT / 64) + wv] = bm;
+                    if (lane == 0 && (uint32_t)((k0 + k) * (NTW / 64) + wv) < (uint32_t)Cfg::HMW) st.u.m.hitmap[(k0 + k) * (NTW / 64) + wv] = bm;
                 }
             }
         }
-        if (MKT_TOUCH) asm volatile("" ::"v"(touch0), "v"(touch1));      // (keeps the two registers reserved until the loads have landed)
         __syncthreads();
         STAMP(1);
         STOP_AFTER(1)
@@ -610,16 +541,16 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         STAMP(2);
         STOP_AFTER(2)
         // ---- line heads: eight aligned 16-byte chunks per line, from the vector that holds the newline in front of it (the
-        //      fabric delivers most of them a second time), with their whitespace bits.  Only the block's last windows can
+        //      fabric delivers most of them a second time), with their separator bits (byte <= 0x20).  Only the block's last windows can
         //      reach past the end of the text: every other tile takes the path without the per-lane end checks.
         {
-            constexpr int HPT = (Cfg::LCAP * Cfg::HCH + NT - 1) / NT;      // chunks per lane
+            constexpr int HPT = (Cfg::LCAP * Cfg::HCH + NTW - 1) / NTW;    // chunks per lane
             auto heads = [&](auto edge_c) {
                 constexpr bool EDGE = decltype(edge_c)::value;
                 uint4 q[HPT];
 #pragma unroll
                 for (int k = 0; k < HPT; ++k) {                                // all loads first ...
-                    const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
+                    const uint32_t it = (uint32_t)tid + (uint32_t)k * NTW;
                     q[k] = make_uint4(0, 0, 0, 0);
                     if (it < NL * (uint32_t)Cfg::HCH) {
                         const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
@@ -629,7 +560,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 }
 #pragma unroll
                 for (int k = 0; k < HPT; ++k) {                                // ... then the stores and the whitespace bits
-                    const uint32_t it = (uint32_t)tid + (uint32_t)k * NT;
+                    const uint32_t it = (uint32_t)tid + (uint32_t)k * NTW;
                     if (it >= NL * (uint32_t)Cfg::HCH) continue;
                     const uint32_t i = it / (uint32_t)Cfg::HCH, c = it % (uint32_t)Cfg::HCH;
                     uint4 x = q[k];
@@ -647,16 +578,11 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                         }
                     }
                     {   // rows are 33 dwords apart (bank spread for the parse lanes): four dword stores
-#if defined(MKT_HSTRIDE8)
-                        uint2* row = reinterpret_cast<uint2*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + (c << 4)]);
-                        row[0] = make_uint2(x.x, x.y); row[1] = make_uint2(x.z, x.w);
-#else
                         uint32_t* row = reinterpret_cast<uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE) + (c << 4)]);
                         row[0] = x.x; row[1] = x.y; row[2] = x.z; row[3] = x.w;
-#endif
                     }
-                    uint32_t m = pack16(ws_flags(x.x), ws_flags(x.y), ws_flags(x.z), ws_flags(x.w));
-                    if (EDGE && keep < 16u) m &= (1u << keep) - 1u;            // cleared bytes are not whitespace
+                    uint32_t m = pack16(sep_flags(x.x), sep_flags(x.y), sep_flags(x.z), sep_flags(x.w));
+                    if (EDGE && keep < 16u) m &= (1u << keep) - 1u;            // cleared bytes are no separators
                     st.u.m.hmask[i][c] = (uint16_t)m;
                 }
             };
@@ -666,22 +592,11 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         __syncthreads();
         STAMP(9);
         STOP_AFTER(9)
-        if (MKT_TOUCH == 1) touch_next(t + gridDim.x);
 
-        // group phase: lines are dealt round-robin to the four waves (fewer divergent classifier paths per wave)
-#if defined(MKT_ROTATE)
-        // logical lanes: the waves swap roles from tile to tile (parsing fills logical waves 0..2, the group phase runs on
-        // logical waves 2 and 3), so that the four SIMDs of the CU share a tile's work whatever SIMD a wave sits on
-        const uint32_t ltid = ((uint32_t)tid + ((rot & 3u) << 6)) & (uint32_t)(NT - 1);
-        ++rot;
-        const uint32_t rr_id = (ltid >> 6) >= 2u ? (ltid & 63u) * 2u + ((ltid >> 6) - 2u) : 0xFFFFFFu;
-#else
+        // group phase: lines are dealt round-robin to RR waves (fewer divergent classifier paths per wave)
         const uint32_t ltid = (uint32_t)tid;
-        (void)rot;
-        const uint32_t rr_id = ((uint32_t)tid >> 6) < (uint32_t)MKT_RR ? ((uint32_t)tid & 63u) * MKT_RR + ((uint32_t)tid >> 6) : 0xFFFFFFu;
-#endif
-        {   // one lane per line (LCAP < NT); the line masks are the waves' ballots
-            static_assert(Cfg::LCAP <= NT, "one parse lane per line");
+        const uint32_t rr_id = ((uint32_t)tid >> 6) < (uint32_t)RR ? ((uint32_t)tid & 63u) * RR + ((uint32_t)tid >> 6) : 0xFFFFFFu;
+        {   // one lane per line (LCAP <= NTW); the line masks are the waves' ballots
             const uint32_t i = ltid;
             uint32_t lb = 0, fl = 0;
             if (i < NL) { fast_parse(st, tv, P, G, i); lb = st.bits[i]; fl = st.flag[i]; }
@@ -696,11 +611,11 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 if (b_t0) atomicAdd(&st.c_t0, (uint32_t)__popcll(b_t0));
                 if (b_t1) atomicAdd(&st.c_t1, (uint32_t)__popcll(b_t1));
             }
+            if (NTW < 256 && tid < 4 && tid >= NTW / 64) { st.m_surv[tid] = 0; st.m_eqp[tid] = 0; st.m_r1[tid] = 0; st.m_r2[tid] = 0; st.m_start[tid] = 0; }
         }
         __syncthreads();
         STAMP(3);
         STOP_AFTER(3)
-        if (MKT_TOUCH == 2) touch_next(t + gridDim.x);
         const uint32_t NLe = fast_nle(st);
         const uint32_t first_idx = NL - st.c_t0 < NLe ? NL - st.c_t0 : NLe;
         const uint32_t end_idx = NL - st.c_t1 < NLe ? NL - st.c_t1 : NLe;
@@ -710,28 +625,10 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             if (!st.abn && i >= first_idx && i < NLe && mask_bit(st.m_surv, i)) s0 = fast_is_start(st, tv, G, i);
             const uint64_t b = __ballot(s0);
             if ((tid & 63) == 0) st.m_start[ltid >> 6] = b;
-#if defined(MKT_GROUP1)
-            // the tile's own group starts, compacted in line order: the group phase then runs with full lanes on ONE wave
-            const bool own = s0 && i < end_idx;
-            const uint64_t bo = __ballot(own);
-            if (own) st.start_list[((ltid >> 6) << 6) + (uint32_t)__popcll(bo & ((1ull << (tid & 63)) - 1ull))] = (uint8_t)i;
-            if ((tid & 63) == 0) st.start_cnt[ltid >> 6] = (uint32_t)__popcll(bo);
-            if (i >= first_idx && i < end_idx) { st.u.g.g_info[i] = 0; st.u.g.g_plen[i] = 0; st.u.g.g_slen[i] = 0; }     // (the sums read every line of the tile)
-#endif
         }
         __syncthreads();
         STAMP(10);
-#if defined(MKT_GROUP1)
-        const uint32_t sc0 = st.start_cnt[0], sc1 = sc0 + st.start_cnt[1], sc2 = sc1 + st.start_cnt[2], nst = sc2 + st.start_cnt[3];
-        auto start_line = [&](uint32_t L) -> uint32_t {
-            const uint32_t w = (L >= sc0 ? 1u : 0u) + (L >= sc1 ? 1u : 0u) + (L >= sc2 ? 1u : 0u);
-            const uint32_t base = w == 0u ? 0u : (w == 1u ? sc0 : (w == 2u ? sc1 : sc2));
-            return st.start_list[(w << 6) + (L - base)];
-        };
-        if (!st.abn && (tid >> 6) == 3) for (uint32_t L = (uint32_t)tid & 63u; L < nst; L += 64u) fast_group(st, tv, P, G, start_line(L));
-#else
-        if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * MKT_RR) fast_group(st, tv, P, G, i);
-#endif
+        if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * RR) fast_group(st, tv, P, G, i);
         __syncthreads();
         STAMP(4);
         STOP_AFTER(4)
@@ -741,35 +638,6 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         {
             auto& g = st.u.g;
             const uint32_t i = first_idx + tid;
-#if defined(MKT_SUMS64)
-            uint64_t ca = 0, cb = 0;
-            uint32_t info = 0;
-            if (i < NLe && !st.abn) {
-                if (i < end_idx) {
-                    info = g.g_info[i];
-                    if (info & GI_START) ca += 1ull;
-                    if (info & GI_EMIT) ca += 1ull << 16;
-                    if ((info & GI_START) && (info & GI_COUNTER) == C_SELFCIRCLE) ca += 1ull << 32;
-                    cb = g.g_plen[i];
-                }
-                if (P.write_sam) cb |= (uint64_t)fast_line_sam(st, G, i) << 32;
-            }
-            uint64_t ea = ca, eb = cb, ta, tb;
-            block_exscan2(ea, eb, ta, tb, scan);
-            if (i < NLe && !st.abn) {
-                g.x_sam[i] = (uint32_t)(eb >> 32);
-                if (i < end_idx) {
-                    g.x_grp[i] = (uint8_t)(ea & 0xFFu); g.x_sc[i] = (uint8_t)((ea >> 32) & 0xFFu); g.x_emit[i] = (uint8_t)((ea >> 16) & 0xFFu);
-                    g.x_pair[i] = (uint16_t)(eb & 0xFFFFu);
-                    if (info & GI_EMIT) g.em_idx[(ea >> 16) & 0xFFu] = (uint8_t)i;
-                }
-            }
-            if (tid == 0) {
-                st.sums.groups = (uint32_t)(ta & 0xFFFFu); st.sums.emitted = (uint32_t)((ta >> 16) & 0xFFFFu); st.sums.sc = (uint32_t)((ta >> 32) & 0xFFFFu);
-                st.sums.pair_bytes = (uint32_t)tb; st.sums.sam_bytes = tb >> 32;
-                if ((uint32_t)tb > 0xFFFFu) st.abn = AB_PAIR_BYTES;          // 16-bit in-tile offsets
-            }
-#else
             // counts packed 10 bits apiece (<= LCAP each), .pairs bytes, .sam bytes: three 32-bit scans
             uint32_t cc = 0, cp = 0, cs = 0;
             uint32_t info = 0;
@@ -784,7 +652,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 if (P.write_sam) cs = fast_line_sam(st, G, i);
             }
             uint32_t ec = cc, ep = cp, es = cs, tc, tp, ts;
-            block_exscan3<false>(ec, ep, es, tc, tp, ts, scan);
+            block_exscan3<NTW / 64>(ec, ep, es, tc, tp, ts, scan);
             if (tid == 0) {
                 // the tile's totals, and with them at once its output ranges: the claiming atomic is on its way while the other
                 // lanes store their offsets (one barrier fewer than a phase of its own)
@@ -806,86 +674,33 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                     if (info & GI_EMIT) g.em_idx[(ec >> 10) & 0xFFu] = (uint8_t)i;
                 }
             }
-#endif
         }
         __syncthreads();
         STAMP(6);
         STOP_AFTER(6)
-        if (PF > 0 && t + gridDim.x < a.ntiles) prefetch(t + gridDim.x);
-#if defined(MKT_SUMS64)
-        if (st.abn) {
-#else
         if (st.abn & 0xFFu) {                                 // leave the whole tile to the generic kernel
-#endif
             if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
             __syncthreads();
             continue;
         }
-
         // ---- output ranges: claimed by lane 0 at the end of the sums phase (above)
-#if defined(MKT_SUMS64)
-        if (tid == 0) {
-            const uint32_t e = claim_ranges(a, region, st.sums, st.base, st.region_pair0, st.region_sam0, s_out);
-            st.region_id = region;
-            if (e) lds_or(&st.abn, e << 8);
-        } else if (tid == 4) a.tile_groups[t] = (uint64_t)st.sums.groups | ((uint64_t)st.sums.emitted << 32);
-        __syncthreads();
-#endif
         STAMP(7);
         STOP_AFTER(7)
-        if (MKT_TOUCH == 3) touch_next(t + gridDim.x);
 
         // ---- emit ----------------------------------------------------------------------------------
         const uint32_t total = st.sums.pair_bytes;
         uint8_t* const dst = s_out.pairs + st.base.pair_bytes;
-#if defined(MKT_GROUP1)
-        if ((tid >> 6) == 0) for (uint32_t L = (uint32_t)tid; L < nst; L += 64u) {
-            const uint32_t i = start_line(L);
+        for (uint32_t i = first_idx + ltid; i < end_idx; i += NTW) {
             fast_account(st, s_out, t, i);
             fast_last(st, G, &a.tile_last[t], i);
         }
-#else
-        for (uint32_t i = first_idx + ltid; i < end_idx; i += NT) {
-            fast_account(st, s_out, t, i);
-            fast_last(st, G, &a.tile_last[t], i);
-        }
-#endif
-        // .pairs: one lane per reported pair writes its whole line (fast_emit_line).  Experiment switch MKT_EMIT_STAGED: into LDS
-        // first (the dead parse records), then out as aligned 16-byte vectors of the tile's ONE contiguous range
-#if defined(MKT_EMIT_STAGED)
-        constexpr uint32_t STAGE_CAP = (uint32_t)sizeof(st.rc.f) & ~15u;
-        const bool staged = total != 0u && total + 16u <= STAGE_CAP;
-#else
-        const bool staged = false;                             // (measured: 1.6 % slower than the direct stores)
-#endif
-        uint8_t* const stage = reinterpret_cast<uint8_t*>(&st.rc.f);
-        const uint32_t a16 = (uint32_t)((uintptr_t)dst & 15u);
-        if (total && st.base.pair_bytes + total <= s_out.pairs_cap && staged) {
+        // .pairs: one lane per reported pair writes its whole line (fast_emit_line), on the waves the accounting left idle
+        if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
             const auto& g = st.u.g;
-            for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted; e += NT) {      // (the two waves the accounting left idle)
-                const uint32_t i = g.em_idx[e];
-                fast_emit_line(st, g.g_slot[i], g.g_plen[i], stage + a16 + g.x_pair[i]);
-            }
-        } else if (total && st.base.pair_bytes + total <= s_out.pairs_cap) {
-            const auto& g = st.u.g;
-#ifndef MKT_EMIT_PARTS
-#define MKT_EMIT_PARTS 1
-#endif
-#if MKT_EMIT_PARTS == 1
-            for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted; e += NT) {      // (the two waves the accounting left idle)
+            for (uint32_t e = (ltid + (uint32_t)(NTW / 2)) & (uint32_t)(NTW - 1); e < st.sums.emitted; e += NTW) {
                 const uint32_t i = g.em_idx[e];
                 fast_emit_line(st, g.g_slot[i], g.g_plen[i], dst + g.x_pair[i]);
             }
-#else
-            // MKT_EMIT_PARTS lanes per line, each a contiguous share of its bytes
-            for (uint32_t e = (ltid + 128u) & (uint32_t)(NT - 1); e < st.sums.emitted * (uint32_t)MKT_EMIT_PARTS; e += NT) {
-                const uint32_t i = g.em_idx[e / (uint32_t)MKT_EMIT_PARTS], part = e % (uint32_t)MKT_EMIT_PARTS;
-                const uint32_t plen = g.g_plen[i];
-                const uint32_t lo = (mul24(plen, part) / (uint32_t)MKT_EMIT_PARTS + 3u) & ~3u, hi0 = (mul24(plen, part + 1u) / (uint32_t)MKT_EMIT_PARTS + 3u) & ~3u;
-                const uint32_t hi = part + 1u == (uint32_t)MKT_EMIT_PARTS ? plen : (hi0 < plen ? hi0 : plen);
-                fast_emit_part(st, g.g_slot[i], plen, dst + g.x_pair[i], lo < plen ? lo : plen, hi);
-            }
-#endif
         }
         __syncthreads();
         STAMP(11);
@@ -893,48 +708,6 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         // cache line would queue up behind each other)
         if (tid < (int)C_COUNT) wg_cnt[tid] += st.cnt[tid];
         if (tid == 0 && (st.abn >> 8)) atomicOr(&a.res->err, st.abn >> 8);
-        if (staged && st.base.pair_bytes + total <= s_out.pairs_cap) {
-            // staged bytes [a16, a16 + total) <-> dst[0, total): vector v is staging [16 v, 16 v + 16) = (dst - a16)[16 v, ...)
-            uint8_t* const gbase = dst - a16;
-            const uint32_t endb = a16 + total, nvec = (endb + 15u) >> 4;
-            for (uint32_t v = (uint32_t)tid; v < nvec; v += NT) {
-                const uint32_t b0 = v << 4;
-                if (b0 >= a16 && b0 + 16u <= endb) *reinterpret_cast<uint4*>(gbase + b0) = *reinterpret_cast<const uint4*>(stage + b0);
-                else {
-                    const uint32_t lo = b0 > a16 ? b0 : a16, hi = b0 + 16u < endb ? b0 + 16u : endb;
-                    for (uint32_t k = lo; k < hi; ++k) gbase[k] = stage[k];
-                }
-            }
-            if (P.write_sam) __syncthreads();                       // (the .sam copy below builds its line list in the same LDS)
-        }
-#if defined(MKT_SAM_LINEWISE)
-        if (P.write_sam && st.sums.sam_bytes) {
-            const uint64_t gos = st.base.sam_bytes;
-            if (gos + st.sums.sam_bytes <= s_out.sam_cap) {
-                // one wave per emitting line, straight from the text in global memory (L2): 16-byte stores on
-                // destination-aligned chunks, single bytes at the two ends
-                const int wv = tid >> 6, lane = tid & 63;
-                for (uint32_t i = first_idx + wv; i < NLe; i += NT / 64) {
-                    if (!mask_bit(st.m_emit, i)) continue;
-                    const uint8_t* src = a.text + G.w0 + st.goff[i];
-                    const uint32_t len = fast_line_sam(st, G, i);
-                    uint8_t* dst = s_out.sam + gos + st.u.g.x_sam[i];
-                    const uint32_t head = (uint32_t)((16u - ((uintptr_t)dst & 15u)) & 15u);
-                    const uint32_t h = head < len ? head : len;
-                    if ((uint32_t)lane < h) dst[lane] = src[lane];
-                    const uint32_t nv = (len - h) >> 4;
-                    for (uint32_t v = lane; v < nv; v += 64) {
-                        const uint32_t o = h + (v << 4);
-                        uint4 x;
-                        __builtin_memcpy(&x, src + o, 16);
-                        *reinterpret_cast<uint4*>(dst + o) = x;
-                    }
-                    const uint32_t t0 = h + (nv << 4);
-                    if ((uint32_t)lane < len - t0) dst[t0 + lane] = src[t0 + lane];
-                }
-            }
-        }
-#else
         // The tile's .sam bytes are ONE contiguous range of the output (the emitting lines in order): copied destination first --
         // every thread takes aligned 16-byte vectors of that range (full lanes, coalesced stores) and finds the line a vector
         // lies in by bisection over the emitting lines' offsets; the text comes straight from global memory (L2).
@@ -944,7 +717,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
         uint32_t E = 0;
         if (sam_copy) {
             E = (uint32_t)(__popcll(st.m_emit[0]) + __popcll(st.m_emit[1]) + __popcll(st.m_emit[2]) + __popcll(st.m_emit[3]));
-            for (uint32_t i = first_idx + (uint32_t)tid; i < NLe; i += NT) {
+            for (uint32_t i = first_idx + (uint32_t)tid; i < NLe; i += NTW) {
                 if (!mask_bit(st.m_emit, i)) continue;
                 uint32_t k = (uint32_t)__popcll(st.m_emit[i >> 6] & ((1ull << (i & 63u)) - 1ull));
                 for (uint32_t w = 0; w < (i >> 6); ++w) k += (uint32_t)__popcll(st.m_emit[w]);
@@ -968,7 +741,7 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
             const uint32_t nv = (total - head) >> 4, tail0 = head + (nv << 4);
             if ((uint32_t)tid < head) { const uint32_t k = line_of((uint32_t)tid); *MKT_GLOBAL(uint8_t, dbase + tid) = tbase[es[k] + (uint32_t)tid - eo[k]]; }
             if ((uint32_t)tid < total - tail0) { const uint32_t d = tail0 + (uint32_t)tid, k = line_of(d); *MKT_GLOBAL(uint8_t, dbase + d) = tbase[es[k] + d - eo[k]]; }
-            for (uint32_t v = (uint32_t)tid; v < nv; v += NT) {
+            for (uint32_t v = (uint32_t)tid; v < nv; v += NTW) {
                 const uint32_t d = head + (v << 4);
                 const uint32_t k = line_of(d);
                 const uint32_t o = d - eo[k], left = eo[k + 1u] - d;               // bytes of line k from here on
@@ -1003,7 +776,6 @@ __global__ __launch_bounds__(NT, MKT_WPS) void k_fast(KArgs a) {      // 4 waves
                 *MKT_GLOBAL(uint4, dbase + d) = x;
             }
         }
-#endif
         __syncthreads();                                           // every lane is done with this tile's state
         STAMP(8);
     }
@@ -1214,30 +986,39 @@ hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_grou
 }
 
 // ---------------------------------------------------------------------------------------------
-typedef TileCfg<MKT_LEAN_TILE, MKT_LEAN_HB, MKT_LEAN_HF, 512, 4> CfgFast;      // same tile index space as the lean kernel
+typedef FastCfg<kLeanTile, kLeanHB, kLeanHF, kLeanLCAP> CfgLean;
+typedef TileCfg<kLeanTile, kLeanHB, kLeanHF, 512, 4> CfgFast;                 // same tile index space as the lean kernel
 typedef TileCfg<kMidTile, kMidHB, kMidHF, 512, 4> CfgMid;                    // ... and as its variants for shorter lines
 typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
 typedef FastCfg<kMidTile, kMidHB, kMidHF, kMidLCAP> CfgLeanMid;
 typedef FastCfg<kDenseTile, kDenseHB, kDenseHF, kDenseLCAP> CfgLeanDense;
+// one WAVE per tile (a workgroup of 64 threads: its barriers are no-ops, every wave of the CU runs on its own)
+typedef FastCfg<kWaveTile, kWaveHB, kWaveHF, kWaveLCAP, kWaveGCAP> CfgLeanWave;
+typedef TileCfg<kWaveTile, kWaveHB, kWaveHF, 256, 4> CfgWave;
 
 uint32_t tile_bytes(int cfg) {
-    return cfg == CFG_SMALL ? CfgSmall::TILE : (cfg == CFG_DENSE ? CfgDense::TILE : (cfg == CFG_MID ? CfgMid::TILE : CfgFast::TILE));
+    return cfg == CFG_SMALL ? CfgSmall::TILE : (cfg == CFG_DENSE ? CfgDense::TILE : (cfg == CFG_MID ? CfgMid::TILE : (cfg == CFG_WAVE ? CfgWave::TILE : CfgFast::TILE)));
 }
+
+// 4 workgroups of 256 threads per CU (k_fast is compiled for 4 waves per SIMD); wave-wide workgroups: as many as the LDS admits
+uint32_t fast_max_workgroups(int cfg) { return cfg == CFG_WAVE ? 256u * (uint32_t)(160 * 1024 / (sizeof(FastState<CfgLeanWave>) + 512)) : 256u * 4u; }
 
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
     if (cfg == CFG_SMALL) hipLaunchKernelGGL(k_tiles<CfgSmall>, dim3(grid), dim3(NT), 0, s, a);
     else if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_tiles<CfgDense>, dim3(grid), dim3(NT), 0, s, a);
     else if (cfg == CFG_MID) hipLaunchKernelGGL(k_tiles<CfgMid>, dim3(grid), dim3(NT), 0, s, a);
+    else if (cfg == CFG_WAVE) hipLaunchKernelGGL(k_tiles<CfgWave>, dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(k_tiles<CfgFast>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
-    if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_fast<CfgLeanDense>, dim3(grid), dim3(NT), 0, s, a);
-    else if (cfg == CFG_MID) hipLaunchKernelGGL(k_fast<CfgLeanMid>, dim3(grid), dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL(k_fast<CfgLean>, dim3(grid), dim3(NT), 0, s, a);
+    if (cfg == CFG_DENSE) hipLaunchKernelGGL((k_fast<CfgLeanDense, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
+    else if (cfg == CFG_MID) hipLaunchKernelGGL((k_fast<CfgLeanMid, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
+    else if (cfg == CFG_WAVE) hipLaunchKernelGGL((k_fast<CfgLeanWave, 64, 1, 2>), dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((k_fast<CfgLean, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {

@@ -7,7 +7,7 @@
 
 namespace mkt {
 
-enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2, CFG_MID = 3 };      // tile geometries: 48 KiB lean, 256 B generic only, 16 KiB lean, 32 KiB lean
+enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2, CFG_MID = 3, CFG_WAVE = 4 };      // tile geometries: 48 KiB lean, 256 B generic only, 16 KiB lean, 32 KiB lean, 16 KiB one wave per tile
 
 // totals of the blocks a context has finished, kept on the device so that resident blocks chain
 // without a host round trip
@@ -56,6 +56,7 @@ struct KArgs {
 };
 
 uint32_t tile_bytes(int cfg);
+uint32_t fast_max_workgroups(int cfg);      // grid of the lean kernel: the workgroups that are resident at once on 256 CUs
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s);
 hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s);
 uint32_t finish_chunk_tiles();

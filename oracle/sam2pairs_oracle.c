@@ -415,7 +415,13 @@ int orc_selfcircle_logged(uint64_t g, uint64_t K, int threads) {
     return i < loaded / W;
 }
 
-int orc_run(const char *text, size_t n, const orc_params *p, orc_buf *pairs, orc_buf *sam, orc_stats *st) {
+/* One SHARD of an input (a whole number of QNAME groups): every group is classified unless drop_last (the shard holds the
+ * end of the input: quirk Q1), and Q2 is evaluated at the groups' GLOBAL indices group_offset + g out of total_groups
+ * (0: this shard is the whole input).  The reference has no shards: this is its closed form applied to a
+ * part, so that the parts' counters add up to the whole input's log.  sc_local (optional): the shard-local indices of the
+ * self-circle groups, uint64 each, for callers that only learn total_groups after every shard has run. */
+int orc_run_shard(const char *text, size_t n, const orc_params *p, int drop_last, uint64_t group_offset, uint64_t total_groups,
+                  orc_buf *pairs, orc_buf *sam, orc_buf *sc_local, orc_stats *st) {
     /* pass 1: lines -> surviving records, grouped by run-length QNAME equality
      * (sam2pairs.cpp:116-131, pairutil.h:136-177). */
     size_t cap = 1 << 16, nrec = 0, ngrp = 0, gcap = 1 << 15;
@@ -446,14 +452,16 @@ int orc_run(const char *text, size_t n, const orc_params *p, orc_buf *pairs, orc
     st->groups = ngrp;                           /* K, including the dropped last group */
 
     /* pass 2: classify groups 0..K-2 (Q1) */
-    uint64_t K = ngrp;
-    for (uint64_t g = 0; g + 1 < K; ++g) {
+    uint64_t K = total_groups ? total_groups : group_offset + ngrp;
+    uint64_t gend = drop_last ? (ngrp ? ngrp - 1 : 0) : ngrp;
+    for (uint64_t g = 0; g < gend; ++g) {
         const rec *grp = recs + gstart[g];
-        size_t gn = gstart[g + 1] - gstart[g];
+        size_t gn = (g + 1 < ngrp ? gstart[g + 1] : nrec) - gstart[g];
         verdict v;
         if (p->mode == ORC_MODE_FLASH) classify_flash(grp, gn, p->ratio, &v);
         else classify_unc(grp, gn, p->ratio, &v);
-        bump(st, v.counter, v.counter == C_SELFCIRCLE ? orc_selfcircle_logged(g, K, p->threads) : 0);
+        bump(st, v.counter, v.counter == C_SELFCIRCLE ? orc_selfcircle_logged(group_offset + g, K, p->threads) : 0);
+        if (v.counter == C_SELFCIRCLE && sc_local) { uint64_t gi = g; buf_put(sc_local, (const char *)&gi, sizeof gi); }
         if (!v.emit) continue;
         ++st->pairs;
         /* rid \t chrA \t posA \t chrB \t posB \t sA \t sB \n  (flash2pairs.h:60-63,123-127) */
@@ -468,6 +476,28 @@ int orc_run(const char *text, size_t n, const orc_params *p, orc_buf *pairs, orc
     free(recs);
     free(gstart);
     return 0;
+}
+
+int orc_run(const char *text, size_t n, const orc_params *p, orc_buf *pairs, orc_buf *sam, orc_stats *st) {
+    return orc_run_shard(text, n, p, 1, 0, 0, pairs, sam, NULL, st);
+}
+
+/* Order-independent 64-bit checksum of the lines of a buffer (sum over the lines of a mixed FNV-1a of the line's bytes,
+ * newline excluded; a last line without newline counts): equal multisets of lines <=> equal sums, up to 2^-64.  The tests
+ * compare outputs of 10^8 lines with it (the driver's canonical form is the SORTED output, microcket:480). */
+uint64_t orc_lines_checksum(const char *buf, size_t n, uint64_t *lines) {
+    uint64_t sum = 0, cnt = 0, h = 0xcbf29ce484222325ull;
+    int open = 0;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char c = (unsigned char)buf[i];
+        if (c == '\n') {
+            h ^= h >> 29; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+            sum += h; ++cnt; h = 0xcbf29ce484222325ull; open = 0;
+        } else { h = (h ^ c) * 0x100000001b3ull; open = 1; }
+    }
+    if (open) { h ^= h >> 29; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 32; sum += h; ++cnt; }
+    if (lines) *lines = cnt;
+    return sum;
 }
 
 /* The 8-line log, sam2pairs.cpp:211-218. */

@@ -29,6 +29,9 @@ typedef struct {
 } orc_stats;
 
 int orc_run(const char *text, size_t n, const orc_params *p, orc_buf *pairs, orc_buf *sam, orc_stats *st);
+int orc_run_shard(const char *text, size_t n, const orc_params *p, int drop_last, uint64_t group_offset, uint64_t total_groups,
+                  orc_buf *pairs, orc_buf *sam, orc_buf *sc_local, orc_stats *st);
+uint64_t orc_lines_checksum(const char *buf, size_t n, uint64_t *lines);
 int orc_format_log(const orc_stats *st, char *out, size_t cap);
 int orc_selfcircle_logged(uint64_t g, uint64_t K, int threads);
 void orc_buf_free(orc_buf *b);

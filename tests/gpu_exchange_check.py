@@ -23,7 +23,7 @@ with m.Context("unc", 0.5, 10, False, 4, device=0, extensions=ext, ordered=True)
 po = util.oracle_run(text, "unc", 4, 0.5, 10, False)[0]
 assert want == util.expected_dups(po, lanes)
 assert 0 < dups < total
-for world in (2, 3):
+for world in (2, 3, 4):      # 4 ranks, mm10, 100 bp, 4 lanes: the shape of BASELINE.json configs[4] (C5)
     cuts = shard.cut_points(text, world, min_mapq=10)
     ctxs = [m.Context("unc", 0.5, 10, False, 4, device=0, extensions=ext) for _ in range(world)]
     for r in reversed(range(world)):      # the name tables fill in different orders

@@ -280,27 +280,79 @@ def _line_multiset_checksum(buf: bytes) -> int:
 
 
 def test_full_size_properties():
-    """BASELINE.json configs[1] size (100 M pairs, ~92 GB resident): size-independent properties.
-      * pairs == trans + cis10K + cis1K + cis0 (every emitting counter emits exactly one line);
-      * idempotence: a second pass gives identical statistics;
-      * block-cut independence on a 4 M-pair slice: different block sizes and tile configs give the
-        same multiset of output lines (order-independent checksum) as the CPU oracle on that slice."""
+    """BASELINE.json configs[1] size (100 M pairs, ~92 GB resident), EVERY block against the CPU oracle.
+      * each of the 48 resident blocks (2^21 pairs, 1.9 GB of text; the last one holds the input's tail group, quirk Q1): the
+        block's .pairs bytes as they sit in HBM after its pass == the oracle's output for that block's text as line multisets
+        (same byte count, same line count, same order-independent 64-bit checksum); the oracle runs per block in a pool of host
+        threads (ctypes releases the GIL), nothing on the GPU is re-run for the comparison;
+      * the whole run's statistics == the blocks' oracle counters added up, with the logged selfCircle (quirk Q2) evaluated at
+        the global group indices: the .log is byte-identical to what the reference would write for the 94 GB input;
+      * pairs == trans + cis10K + cis1K + cis0; idempotence (a second pass gives identical statistics); block-cut independence
+        (1.9 GB and 0.47 GB blocks of a 16 M-pair data set give the same statistics);
+      * a 4 M-pair slice through the STREAMING path (host bytes, 64 MiB blocks) against the oracle as well."""
     _need_gpu()
+    import concurrent.futures as cf
     pairs = int(os.environ.get("MKT_TEST_FULL_PAIRS", 100_000_000))
-    with m.Context("unc", 0.5, 10, False, 8, device=0, tiles=m.TILES_FAST) as c:
+    T = 8
+    workers = max(2, min(16, (os.cpu_count() or 4) - 2))
+    with m.Context("unc", 0.5, 10, False, T, device=0, tiles=m.TILES_AUTO) as c:
         ds = c.dataset(20260105, 0, pairs, 1 << 21, tail_group=True)      # bench.py's blocks: 1.9 GB of text each
-        stats = []
-        for _ in range(2):
-            c.reset()
-            for (p, nb, g) in ds.blocks:
+        nb_ = ds.n_blocks
+        results = [None] * nb_
+
+        def check_block(b, text, out_pairs, last):
+            st, (hp, pl, pn), _sam, scl = util.oracle_shard_summary(text, "unc", T, 0.5, 10, False, drop_last=False)
+            gh, gl = util.lines_checksum(out_pairs)
+            return b, st, (hp, pl, pn), (gh, gl, int(out_pairs.size)), scl
+
+        c.reset()
+        pend = []
+        with cf.ThreadPoolExecutor(workers) as ex:
+            for b, (p, nb, g) in enumerate(ds.blocks):
                 c.submit_device(p, nb)
-            stats.append(c.finish(True))
-        a, b = stats
-        assert a.counters() == b.counters() and a.pairs == b.pairs and a.pair_bytes == b.pair_bytes and a.groups == b.groups
+                c.sync()
+                out_pairs, _ = c.fetch_last_block_np()                 # every group of the block, its last one included
+                text = c.copy_to_host_np(p, nb)
+                pend.append(ex.submit(check_block, b, text, out_pairs, b == nb_ - 1))
+                del text, out_pairs
+                while len(pend) >= workers + 2:                         # bounded: at most workers + 2 blocks (2 GB each) on the host
+                    r = pend.pop(0).result()
+                    results[r[0]] = r[1:]
+            for f in pend:
+                r = f.result()
+                results[r[0]] = r[1:]
+        a = c.finish(True)
+        log_gpu = c.format_log(a)
+        # ---- per block: line multisets
+        for b, (st, want, got, scl) in enumerate(results):
+            assert got == want, (b, got, want)
+        # ---- the run: counters added up, quirk Q1 (the input's last group) and Q2 (global indices) applied by the checker
+        K = sum(int(r[0].groups) for r in results)
+        assert a.groups == K
+        tot = dict(lowMap=0, manyHits=0, unpaired=0, selfCircle=0, trans=0, cis10K=0, cis1K=0, cis0=0)
+        off = 0
+        for b, (st, want, got, scl) in enumerate(results):
+            for k in ("lowMap", "manyHits", "unpaired", "trans", "cis10K", "cis1K", "cis0"):
+                tot[k] += int(getattr(st, k))
+            for gi in scl:
+                if off + int(gi) != K - 1 and util.selfcircle_logged(off + int(gi), K, T):
+                    tot["selfCircle"] += 1
+            off += int(st.groups)
+        # the tail group (the generator's dummy last pair, dropped by Q1) was counted by the per-block oracle: take it out again
+        tail_st, _p, _s, tail_sc = util.oracle_shard_summary(c.copy_to_host_np(ds.blocks[-1][0], ds.blocks[-1][1]), "unc", T, 0.5, 10, False, drop_last=True)
+        last_st = results[-1][0]
+        for k in ("lowMap", "manyHits", "unpaired", "trans", "cis10K", "cis1K", "cis0"):
+            tot[k] -= int(getattr(last_st, k)) - int(getattr(tail_st, k))
+        want_log = "".join(f"{k}\t{tot[k] & 0xFFFFFFFF}\n" for k in ("lowMap", "manyHits", "unpaired", "selfCircle", "trans", "cis10K", "cis1K", "cis0")).encode()
+        assert log_gpu == want_log, (log_gpu, want_log)
         assert a.pairs == a.trans + a.cis10K + a.cis1K + a.cis0
-        assert a.groups <= ds.total_groups and a.groups > 0.9 * ds.total_groups
         assert a.bytes_in == ds.total_bytes
-        # slice: first 2 blocks (4 M pairs) against the oracle, by line-multiset checksum
+        # ---- idempotence
+        c.reset()
+        for (p, nb, g) in ds.blocks:
+            c.submit_device(p, nb)
+        b2 = c.finish(True)
+        assert a.counters() == b2.counters() and a.pairs == b2.pairs and a.pair_bytes == b2.pair_bytes and a.groups == b2.groups
         nblk = min(2, ds.n_blocks)
         host = b"".join(c.copy_to_host(p, nb) for (p, nb, g) in ds.blocks[:nblk])
         ds.close()
@@ -316,10 +368,12 @@ def test_full_size_properties():
             cut.append((st2.counters(), st2.pairs, st2.pair_bytes, st2.groups))
             d2.close()
         assert cut[0] == cut[1]
-    po, so, lo, ost = util.oracle_run(host, "unc", 8, 0.5, 10, False)
-    want = _line_multiset_checksum(po)
-    for tiles, block in ((m.TILES_FAST, 0), (m.TILES_FAST, 64 << 20)):
-        with m.Context("unc", 0.5, 10, False, 8, device=0, block_bytes=block, tiles=tiles) as c:
+    # ---- a slice through the streaming path (host bytes in, 64 MiB blocks and one big block)
+    st, (hp, pl, pn), _sam, _scl = util.oracle_shard_summary(host, "unc", T, 0.5, 10, False, drop_last=True)
+    po, so, lo, ost = util.oracle_run(host, "unc", T, 0.5, 10, False)
+    assert util.lines_checksum(po)[0] == hp
+    for tiles, block in ((m.TILES_AUTO, 0), (m.TILES_FAST, 64 << 20)):
+        with m.Context("unc", 0.5, 10, False, T, device=0, block_bytes=block, tiles=tiles) as c:
             p, s, st, log = c.run_bytes(host, chunk=256 << 20)
         assert log == lo
-        assert len(p) == len(po) and _line_multiset_checksum(p) == want
+        assert len(p) == len(po) and util.lines_checksum(p) == (hp, pl)

@@ -72,6 +72,58 @@ def oracle_run(text: bytes, mode, threads=4, ratio=0.5, mapq=10, sam=True):
     return pairs, s, log.value, st
 
 
+def _oracle_lib():
+    global _oracle
+    ensure_built()
+    if _oracle is None:
+        _oracle = C.CDLL(ORACLE_SO)
+    _oracle.orc_lines_checksum.restype = C.c_uint64
+    _oracle.orc_lines_checksum.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64)]
+    _oracle.orc_run_shard.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return _oracle
+
+
+def lines_checksum(buf):
+    """(order-independent 64-bit checksum of the lines, number of lines) of bytes or a numpy uint8 array (oracle/: checker only)."""
+    L = _oracle_lib()
+    n = C.c_uint64()
+    if isinstance(buf, (bytes, bytearray)):
+        h = L.orc_lines_checksum(C.c_char_p(bytes(buf)), len(buf), C.byref(n))
+    else:
+        h = L.orc_lines_checksum(C.c_void_p(buf.ctypes.data), buf.size, C.byref(n))
+    return int(h), int(n.value)
+
+
+def oracle_shard_summary(text, mode, threads=4, ratio=0.5, mapq=10, sam=False, drop_last=False):
+    """One shard (whole QNAME groups; numpy uint8 array or bytes) through the CPU restatement without keeping its outputs:
+    returns (stats, (pairs checksum, lines, bytes), (sam checksum, lines, bytes), local indices of the self-circle groups).
+    The calls release the GIL: run several shards in a thread pool."""
+    import numpy as np
+    L = _oracle_lib()
+    if isinstance(mode, str):
+        mode = MODES[mode]
+    p = _OP(mode, threads, ratio, mapq, 1 if sam else 0)
+    a, b, sc, st = _OB(), _OB(), _OB(), OStats()
+    if isinstance(text, (bytes, bytearray)):
+        ptr, n = C.cast(C.c_char_p(bytes(text)), C.c_void_p), len(text)
+    else:
+        ptr, n = C.c_void_p(text.ctypes.data), text.size
+    rc = L.orc_run_shard(ptr, n, C.byref(p), 1 if drop_last else 0, 0, 1 << 62, C.byref(a), C.byref(b), C.byref(sc), C.byref(st))
+    assert rc == 0
+    ln = C.c_uint64()
+    hp = L.orc_lines_checksum(C.c_void_p(a.p), a.n, C.byref(ln)); pl = int(ln.value)
+    hs = L.orc_lines_checksum(C.c_void_p(b.p), b.n, C.byref(ln)); sl = int(ln.value)
+    scl = np.frombuffer(C.string_at(sc.p, sc.n), dtype=np.uint64).copy() if sc.n else np.zeros(0, dtype=np.uint64)
+    out = (st, (int(hp), pl, int(a.n)), (int(hs), sl, int(b.n)), scl)
+    for x in (a, b, sc):
+        L.orc_buf_free(C.byref(x))
+    return out
+
+
+def selfcircle_logged(g, K, threads):
+    return bool(_oracle_lib().orc_selfcircle_logged(C.c_uint64(int(g)), C.c_uint64(int(K)), C.c_int(threads)))
+
+
 def have_ref():
     return os.path.exists(REF_EXE)
 

@@ -2,7 +2,7 @@
 import collections, csv, glob, os, sys
 d = sys.argv[1]
 names = None
-for stop in (1, 2, 3, 4, 6, 7, 0):
+for stop in (1, 2, 9, 3, 4, 6, 7, 0):
     agg = collections.defaultdict(float); n = collections.defaultdict(int)
     for f in glob.glob(os.path.join(d, f"stop{stop}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
