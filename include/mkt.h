@@ -44,7 +44,7 @@ enum {
 };
 
 /* tile geometry selection (tests force the small-tile build to exercise every slow path) */
-enum { MKT_TILES_AUTO = 0, MKT_TILES_FAST = 1, MKT_TILES_SMALL = 2, MKT_TILES_WAVE = 3 };
+enum { MKT_TILES_AUTO = 0, MKT_TILES_FAST = 1, MKT_TILES_SMALL = 2 };
 
 typedef struct mkt_params {
     int32_t mode;              /* MKT_MODE_*                                   argv[2] */

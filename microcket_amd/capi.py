@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 MODE_FLASH, MODE_UNC = 0, 1
-TILES_AUTO, TILES_FAST, TILES_SMALL, TILES_WAVE = 0, 1, 2, 3
+TILES_AUTO, TILES_FAST, TILES_SMALL = 0, 1, 2
 EXT_KEYS = 1
 EXT_LANES = 2
 KEY_BYTES = 24

@@ -30,7 +30,10 @@ struct mkt_ctx {
     mkt_params p;
     Params P;
     int cfg = CFG_FAST;
-    int last_cfg = CFG_FAST;            // geometry of the newest resident block (mkt_fetch_last_block)
+    TileDims dims = {0, 0, 0};          // bytes per tile / halos of the blocks to come (MKT_TILES_AUTO: from the input's line length)
+    bool dims_probed = false;           // the line length of this input has been looked at
+    unsigned long long* d_probe = nullptr; unsigned long long* h_probe = nullptr;      // resident path: newline count of the first MiB
+    TileDims last_dims = {0, 0, 0};     // geometry of the newest resident block (mkt_fetch_last_block)
     const uint8_t* last_text = nullptr; // its text (valid until the next sync: a failed probe block is re-run)
     bool probing = true;                // the next resident block is looked at before more are queued
     hipStream_t stream = nullptr;
@@ -67,7 +70,7 @@ struct mkt_ctx {
     struct InSlot { uint8_t* h = nullptr; uint8_t* d = nullptr; bool busy = false; hipEvent_t h2d = nullptr, k0 = nullptr, k1 = nullptr, done = nullptr; };
     struct OutSlot { uint8_t* d_pairs = nullptr; size_t d_pairs_cap = 0; uint8_t* d_sam = nullptr; size_t d_sam_cap = 0;
                      uint8_t* h = nullptr; size_t h_cap = 0; bool dev_busy = false, host_busy = false; };
-    struct Job { int in_slot, out_slot; size_t n; int cfg; int attempts; };
+    struct Job { int in_slot, out_slot; size_t n; int cfg; TileDims dims; int attempts; };
     struct Chunk { const char* pairs = nullptr; size_t pairs_len = 0; const char* sam = nullptr; size_t sam_len = 0; int out_slot = -1;
                    std::vector<char> own_pairs, own_sam; };
     InSlot in[kIn];
@@ -193,7 +196,9 @@ int mkt_create(const mkt_params* p, mkt_ctx** out) {
     mkt_ctx* c = new mkt_ctx();
     c->p = *p;
     c->P.mode = p->mode; c->P.ratio = p->min_mapped_ratio; c->P.min_mapq = (uint32_t)p->min_mapq; c->P.write_sam = p->write_sam ? 1 : 0;
-    c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : (p->tiles == MKT_TILES_WAVE ? CFG_WAVE : CFG_FAST);
+    c->cfg = p->tiles == MKT_TILES_SMALL ? CFG_SMALL : CFG_FAST;
+    c->dims = c->cfg == CFG_SMALL ? small_dims() : max_dims();
+    c->dims_probed = p->tiles != MKT_TILES_AUTO || p->ordered;
     { const char* e = getenv("MKT_NO_LEAN"); c->no_lean = e && e[0] == '1'; }
     size_t bc = p->block_bytes ? (size_t)p->block_bytes : ((size_t)64 << 20);
     if (bc < 4096) bc = 4096;
@@ -252,6 +257,8 @@ void mkt_destroy(mkt_ctx* c) {
     if (c->d_syn_sizes) (void)hipFree(c->d_syn_sizes);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->d_sc_logged) (void)hipFree(c->d_sc_logged);
+    if (c->d_probe) (void)hipFree(c->d_probe);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     if (c->h_chr_stage) (void)hipHostFree(c->h_chr_stage);
     if (c->d_dd_flags) (void)hipFree(c->d_dd_flags);
     if (c->d_dd_work) (void)hipFree(c->d_dd_work);
@@ -269,14 +276,48 @@ void mkt_destroy(mkt_ctx* c) {
 
 static int ensure_sc_list(mkt_ctx* c, size_t need);
 
-// MKT_TILES_AUTO: when the lean kernel leaves more than one tile in eight to the generic kernel (short lines overflow
-// its line table), the following blocks use the next smaller geometry (48 -> 32 -> 16 KiB tiles)
+// MKT_TILES_AUTO.  The bytes per tile follow the input's line length, looked at BEFORE the first launch (lines of the first MiB:
+// counted by the host on the streaming path, by one small kernel on the resident path); lean_dims() turns it into a window
+// of ~122 lines.  Should a block all the same leave more than one tile in eight to the generic kernel (the lines got shorter on
+// the way), the following blocks use tiles of 0.6 x the bytes.
+static void set_dims_from_avg(mkt_ctx* c, double bytes_per_line) {
+    c->dims_probed = true;
+    if (c->cfg == CFG_SMALL || c->p.tiles != MKT_TILES_AUTO) return;
+    c->dims = lean_dims(bytes_per_line);
+}
+static bool shrink_dims(mkt_ctx* c) {
+    if (c->cfg == CFG_SMALL || c->dims.tile <= 2048u) return false;
+    auto f = [](uint32_t x, uint32_t lo) { uint32_t y = ((uint32_t)(x * 0.6) + 15u) & ~15u; return y < lo ? lo : y; };
+    c->dims.tile = f(c->dims.tile, 2048u); c->dims.hb = f(c->dims.hb, 256u); c->dims.hf = f(c->dims.hf, 512u);
+    return true;
+}
 static bool adapt_geometry(mkt_ctx* c, const BlockResult& r) {
-    if (c->p.tiles == MKT_TILES_AUTO && !c->p.ordered && r.tiles >= 8 && (uint64_t)r.pad * 8 > r.tiles) {
-        if (c->cfg == CFG_FAST) { c->cfg = CFG_MID; return true; }
-        if (c->cfg == CFG_MID) { c->cfg = CFG_DENSE; return true; }
-    }
+    if (c->p.tiles == MKT_TILES_AUTO && !c->p.ordered && r.tiles >= 8 && (uint64_t)r.pad * 8 > r.tiles) return shrink_dims(c);
     return false;
+}
+// bytes per line of device-resident text (its first MiB); the context's stream is idle afterwards.  0: could not tell
+static double probe_device_lines(mkt_ctx* c, const uint8_t* d_text, size_t n) {
+    const size_t look = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+    if (!look) return 0;
+    if (!c->d_probe) {
+        if (hipMalloc((void**)&c->d_probe, sizeof(unsigned long long)) != hipSuccess) return 0;
+        if (hipHostMalloc((void**)&c->h_probe, sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) return 0;
+    }
+    if (hipMemsetAsync(c->d_probe, 0, sizeof(unsigned long long), c->stream) != hipSuccess) return 0;
+    if (launch_count_newlines(d_text, look, c->d_probe, c->stream) != hipSuccess) return 0;
+    if (hipMemcpyAsync(c->h_probe, c->d_probe, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    return *c->h_probe ? (double)look / (double)*c->h_probe : (double)look;
+}
+// a block came back with its line table overflown (E_LINE_TABLE: its lines are shorter than the geometry was chosen for): tiles
+// for ITS line length if that makes them smaller, else 0.6 x the bytes, in the end the 256-byte tiles
+static void smaller_geometry(mkt_ctx* c, const uint8_t* d_text, size_t n) {
+    if (c->cfg != CFG_SMALL && d_text) {
+        const double avg = probe_device_lines(c, d_text, n);
+        const TileDims d = avg > 0 ? lean_dims(avg) : c->dims;
+        if (d.tile < c->dims.tile) { c->dims = d; return; }
+    }
+    if (!shrink_dims(c)) { c->cfg = CFG_SMALL; c->dims = small_dims(); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -284,10 +325,10 @@ static bool adapt_geometry(mkt_ctx* c, const BlockResult& r) {
 // so (streaming path): the block's outputs are also gathered into the contiguous buffers of an output slot, the timing
 // events are the input slot's own, and `done` is recorded behind everything.
 struct StreamOut { uint8_t* gp; size_t gp_cap; uint8_t* gs; size_t gs_cap; hipEvent_t k0, k1, done; };
-static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, size_t slot, const StreamOut* so = nullptr) {
+static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, const TileDims& dims, size_t slot, const StreamOut* so = nullptr) {
     if (((uintptr_t)d_text & 15u) != 0) return fail(c, MKT_E_ARG, "block text must be 16-byte aligned");
     if (n >= kMaxBlock) return fail(c, MKT_E_ARG, "block of %zu bytes: must be < 2 GiB - 64 KiB", n);
-    const uint32_t ntiles = num_tiles((uint32_t)n, tile_bytes(cfg));
+    const uint32_t ntiles = num_tiles((uint32_t)n, dims.tile);
     int rc = ensure_ws(c, ntiles);
     if (rc) return rc;
     // output capacities: .sam is at most the block (+1 for a missing final newline); .pairs is
@@ -298,7 +339,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, s
     KArgs a;
     memset(&a, 0, sizeof a);
     uint8_t* w = c->d_ws;
-    a.text = d_text; a.n = (uint32_t)n; a.ntiles = ntiles; a.P = c->P;
+    a.text = d_text; a.n = (uint32_t)n; a.ntiles = ntiles; a.dims = dims; a.P = c->P;
     a.descA = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.descB = (uint64_t*)w; w += (size_t)ntiles * 8;
     a.descC = (uint64_t*)w; w += (size_t)ntiles * 8;
@@ -499,7 +540,7 @@ static int stream_launch(mkt_ctx* c, const mkt_ctx::Job& j) {
     StreamOut so;
     so.gp = os.d_pairs; so.gp_cap = os.d_pairs_cap; so.gs = os.d_sam; so.gs_cap = os.d_sam_cap;
     so.k0 = is.k0; so.k1 = is.k1; so.done = is.done;
-    return enqueue_block(c, is.d, j.n, j.cfg, c->res_slots - mkt_ctx::kIn + (size_t)j.in_slot, &so);
+    return enqueue_block(c, is.d, j.n, j.cfg, j.dims, c->res_slots - mkt_ctx::kIn + (size_t)j.in_slot, &so);
 }
 
 // c->mu held by lk.  Hands input slot `slot` (n bytes) to the GPU.
@@ -523,8 +564,14 @@ static int stream_enqueue(mkt_ctx* c, std::unique_lock<std::mutex>& lk, int slot
     HIPCHK(c, hipMemcpyAsync(is.d, is.h, n, hipMemcpyHostToDevice, c->s_in));
     HIPCHK(c, hipEventRecord(is.h2d, c->s_in));
     HIPCHK(c, hipStreamWaitEvent(c->stream, is.h2d, 0));
+    if (!c->dims_probed) {                                 // the input's line length, from the first MiB (in pinned host memory)
+        const size_t look = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+        size_t lines = 0;
+        for (const uint8_t* q = is.h, *e = is.h + look; q < e && (q = (const uint8_t*)memchr(q, '\n', (size_t)(e - q))); ++q) ++lines;
+        set_dims_from_avg(c, lines ? (double)look / (double)lines : (double)look);
+    }
     mkt_ctx::Job j;
-    j.in_slot = slot; j.out_slot = oslot; j.n = n; j.cfg = c->cfg; j.attempts = 0;
+    j.in_slot = slot; j.out_slot = oslot; j.n = n; j.cfg = c->cfg; j.dims = c->dims; j.attempts = 0;
     c->bytes_unsynced = 0;
     for (const mkt_ctx::Job& q : c->jobs) c->bytes_unsynced += q.n;     // extension: key-list reservation covers the blocks in flight
     if ((rc = stream_launch(c, j))) return rc;
@@ -546,9 +593,11 @@ static int stream_replay(mkt_ctx* c, const BlockResult& r) {
     if (++j0.attempts > 4) return check_result(c, r);
     bool fixed = false;
     if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && j0.cfg != CFG_SMALL && c->p.tiles == MKT_TILES_AUTO) {
-        const int ncfg = j0.cfg == CFG_FAST ? CFG_MID : (j0.cfg == CFG_MID ? CFG_DENSE : CFG_SMALL);
-        for (mkt_ctx::Job& q : c->jobs) q.cfg = ncfg;
-        if (ncfg != CFG_SMALL) c->cfg = ncfg;              // the stream keeps the geometry that fits its lines (the 256-byte tiles are a last resort per block)
+        const int keep_cfg = c->cfg; const TileDims keep = c->dims;
+        c->cfg = j0.cfg; c->dims = j0.dims;
+        smaller_geometry(c, c->in[j0.in_slot].d, j0.n);
+        for (mkt_ctx::Job& q : c->jobs) { q.cfg = c->cfg; q.dims = c->dims; }
+        if (c->cfg == CFG_SMALL) { c->cfg = keep_cfg; c->dims = keep; }      // (the 256-byte tiles are a last resort per block: the stream keeps its lean geometry)
         fixed = true;
     } else {
         const uint32_t nr = r.nregions ? r.nregions : 1;
@@ -863,14 +912,20 @@ int mkt_submit_device(mkt_ctx* c, const void* d_text, size_t n) {
         // room for as much again as the run holds now, and for this block at the very least
         if ((rc = ensure_sc_list(c, 2 * (size_t)c->acc.sc + sc_estimate(c, n)))) return rc;
     }
+    if (!c->dims_probed) {                                 // the input's line length: newlines of the first MiB, counted on the device
+        const double avg = probe_device_lines(c, (const uint8_t*)d_text, n);
+        if (avg <= 0 && n) return fail(c, MKT_E_HIP, "line-length probe failed: %s", hipGetErrorString(hipGetLastError()));
+        set_dims_from_avg(c, avg);
+    }
     c->bytes_unsynced += n;
     const int cfg_used = c->cfg;
-    int rc = enqueue_block(c, (const uint8_t*)d_text, n, cfg_used, c->res_used);
+    const TileDims dims_used = c->dims;
+    int rc = enqueue_block(c, (const uint8_t*)d_text, n, cfg_used, dims_used, c->res_used);
     if (rc) return rc;
     if (c->res_text.size() < c->res_slots) { c->res_text.resize(c->res_slots); c->res_n.resize(c->res_slots); }
     c->res_text[c->res_used] = (const uint8_t*)d_text; c->res_n[c->res_used] = n;
     ++c->res_used;
-    c->last_n = n; c->last_cfg = cfg_used; c->last_text = (const uint8_t*)d_text;
+    c->last_n = n; c->last_dims = dims_used; c->last_text = (const uint8_t*)d_text;
     c->bytes_in += n;
     return MKT_OK;
 }
@@ -897,13 +952,13 @@ int mkt_sync(mkt_ctx* c) {
         if (r.err) {
             if ((r.err & (E_LINE_TABLE | E_OVF_SLOTS)) && c->p.tiles == MKT_TILES_AUTO && c->cfg != CFG_SMALL && replays < 4 && c->res_text.size() > k) {
                 ++replays;
-                c->cfg = c->cfg == CFG_FAST ? CFG_MID : (c->cfg == CFG_MID ? CFG_DENSE : CFG_SMALL);
-                c->last_cfg = c->cfg;
+                smaller_geometry(c, c->res_text[k], c->res_n[k]);
+                c->last_dims = c->dims;
                 changed = true;
                 DevRun dr;
                 dr.groups = c->acc.groups; dr.sc = c->acc.sc; dr.emitted = c->acc.emitted;
                 HIPCHK(c, hipMemcpy(c->d_run, &dr, sizeof dr, hipMemcpyHostToDevice));
-                for (size_t j = k; j < c->res_used; ++j) if ((rc = enqueue_block(c, c->res_text[j], c->res_n[j], c->cfg, j))) return rc;
+                for (size_t j = k; j < c->res_used; ++j) if ((rc = enqueue_block(c, c->res_text[j], c->res_n[j], c->cfg, c->dims, j))) return rc;
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 fold_timing(c);
                 --k;                                     // look at the same block again
@@ -931,7 +986,7 @@ int mkt_fetch_last_block(mkt_ctx* c, char* pairs, size_t pairs_cap, size_t* pair
     HIPCHK(c, hipStreamSynchronize(c->stream));
     // the last folded result is not kept per block; re-read it from the device workspace
     BlockResult r;
-    const uint32_t ntiles = num_tiles((uint32_t)c->last_n, tile_bytes(c->last_cfg));
+    const uint32_t ntiles = num_tiles((uint32_t)c->last_n, c->last_dims.tile ? c->last_dims.tile : c->dims.tile);
     const uint8_t* w = c->d_ws + ws_tiles_bytes(ntiles) + ws_fixed_bytes();
     HIPCHK(c, hipMemcpy(&r, w, sizeof r, hipMemcpyDeviceToHost));
     if (pairs_len) *pairs_len = (size_t)r.pair_bytes;
@@ -1231,6 +1286,7 @@ int mkt_reset(mkt_ctx* c) {
     // a new input is probed afresh for its densities; the tile geometry learned on the previous input is where its probe
     // starts (a context usually sees one kind of data; a fresh context starts from the largest tiles)
     c->sc_density = 0; c->key_density = 0; c->probing = true;
+    c->dims_probed = c->p.tiles != MKT_TILES_AUTO || c->p.ordered || c->cfg == CFG_SMALL;      // a new input: its own line length
     if (c->d_chr) HIPCHK(c, hipMemsetAsync(c->d_chr, 0, sizeof(ChrTab), c->stream));
     c->res_used = c->res_folded = 0;
     c->h_len = 0;

@@ -400,12 +400,13 @@ struct Seg {
     int32_t segCnt, lclip, rclip, mappable, left0, left1, right0, right1, rightLast;
     uint32_t flag, pos;
     uint32_t chr_off, chr_len;    // RNAME bytes, block relative
+    uint64_t chr_key;             // lean path only: the first eight RNAME bytes as a big-endian number, zero padded
 };
 MKT_HD Seg seg_of(const Rec& r) {
     Seg s;
     s.segCnt = r.segCnt; s.lclip = r.lclip; s.rclip = r.rclip; s.mappable = r.mappable;
     s.left0 = r.left0; s.left1 = r.left1; s.right0 = r.right0; s.right1 = r.right1; s.rightLast = r.rightLast;
-    s.flag = r.flag; s.pos = r.pos; s.chr_off = r.off + r.rn_off; s.chr_len = r.rn_len;
+    s.flag = r.flag; s.pos = r.pos; s.chr_off = r.off + r.rn_off; s.chr_len = r.rn_len; s.chr_key = 0;
     return s;
 }
 
@@ -448,12 +449,23 @@ MKT_HD Verdict verdict_none(uint32_t counter) {
 }
 MKT_HD uint8_t strand_of(uint32_t flag) { return (flag & 16u) ? '-' : '+'; }
 
+// Bytewise comparison of two chromosome names.  Lean path (WIN): the 8-byte keys decide unless both names share their first
+// eight bytes and one of them is longer (names hold no NUL bytes: a zero-padded shorter name sorts first, as std::string does)
+template <bool WIN>
+MKT_HD int chr_cmp(const TextView& tv, uint32_t ao, uint32_t al, uint64_t ak, uint32_t bo, uint32_t bl, uint64_t bk) {
+    if (WIN) {
+        if (ak != bk) return ak < bk ? -1 : 1;
+        if (al <= 8u && bl <= 8u) return 0;
+    }
+    return text_cmp<WIN>(tv, ao, al, bo, bl);
+}
+
 // flash2pairs.h:110-144 / unc2pairs.h:315-348
 template <bool WIN = false>
 MKT_HD Verdict order_and_bin(const TextView& tv, uint32_t c1o, uint32_t c1l, uint32_t pos1, uint8_t s1,
-                             uint32_t c2o, uint32_t c2l, uint32_t pos2, uint8_t s2) {
+                             uint32_t c2o, uint32_t c2l, uint32_t pos2, uint8_t s2, uint64_t k1 = 0, uint64_t k2 = 0) {
     Verdict v;
-    int chrcmp = text_cmp<WIN>(tv, c1o, c1l, c2o, c2l);
+    int chrcmp = chr_cmp<WIN>(tv, c1o, c1l, k1, c2o, c2l, k2);
     if (chrcmp < 0 || (chrcmp == 0 && pos1 < pos2)) {
         v.chrA_off = c1o; v.chrA_len = c1l; v.posA = pos1; v.sA = s1;
         v.chrB_off = c2o; v.chrB_len = c2l; v.posB = pos2; v.sB = s2;
@@ -494,14 +506,14 @@ MKT_HD Verdict classify_flash(const TextView& tv, uint32_t n, const Seg& a, cons
         uint32_t pos1 = a.pos, pos2 = b.pos;
         if (a.lclip > a.rclip) pos1 = (uint32_t)a.right0;
         if (b.lclip > b.rclip) pos2 = (uint32_t)b.right0;
-        return order_and_bin<WIN>(tv, a.chr_off, a.chr_len, pos1, strand_of(a.flag), b.chr_off, b.chr_len, pos2, strand_of(b.flag));
+        return order_and_bin<WIN>(tv, a.chr_off, a.chr_len, pos1, strand_of(a.flag), b.chr_off, b.chr_len, pos2, strand_of(b.flag), a.chr_key, b.chr_key);
     }
     return verdict_none(C_MANYHITS);
 }
 
 template <bool WIN = false>
 MKT_HD bool pairable(const TextView& tv, const Seg& x, const Seg& y, int32_t lo_left, int32_t hi_left, int32_t hi_right) {
-    return text_cmp<WIN>(tv, x.chr_off, x.chr_len, y.chr_off, y.chr_len) == 0 && lo_left < hi_left && hi_right - lo_left <= kMaxPairDist;
+    return chr_cmp<WIN>(tv, x.chr_off, x.chr_len, x.chr_key, y.chr_off, y.chr_len, y.chr_key) == 0 && lo_left < hi_left && hi_right - lo_left <= kMaxPairDist;
 }
 MKT_HD uint32_t clip_side_pos(const Seg& s) { return (uint32_t)(s.lclip > s.rclip ? s.right0 : s.left0); }
 
@@ -512,6 +524,7 @@ MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const 
     if (n1 == 0 || n2 == 0) return verdict_none(C_NONE);        // :52-55
     if (n1 + n2 > 3) return verdict_none(C_NONE);               // :56-59
     uint32_t c1o, c1l, c2o, c2l, pos1 = 0, pos2 = 0;
+    uint64_t k1, k2;
     uint8_t st1, st2;
     if (n1 == 1 && n2 == 1) {                                   // category 0
         const Seg& s1 = r1a; const Seg& s2 = r2a;      // fixed aliases (no run-time choice)
@@ -519,7 +532,7 @@ MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const 
         if (!integrity_1(s2, ratio)) return verdict_none(C_LOWMAP);
         if (s1.segCnt + s2.segCnt > 3) return verdict_none(C_MANYHITS);
         st1 = strand_of(s1.flag); st2 = strand_of(s2.flag);
-        c1o = s1.chr_off; c1l = s1.chr_len; c2o = s2.chr_off; c2l = s2.chr_len;
+        c1o = s1.chr_off; c1l = s1.chr_len; c2o = s2.chr_off; c2l = s2.chr_len; k1 = s1.chr_key; k2 = s2.chr_key;
         if (s1.segCnt == 1 && s2.segCnt == 1) {
             pos1 = (uint32_t)(st1 == '+' ? s1.left0 : s1.right0);
             pos2 = (uint32_t)(st2 == '+' ? s2.left0 : s2.right0);
@@ -569,12 +582,13 @@ MKT_HD Verdict classify_unc(const TextView& tv, uint32_t n1, uint32_t n2, const 
         if (!m0 && !m1) return verdict_none(C_UNPAIRED);        // :229-232 / :287-290
         // the OTHER record of the split read gives the second end
         const uint32_t oo = m0 ? v1.chr_off : v0.chr_off, ol = m0 ? v1.chr_len : v0.chr_len;
+        const uint64_t ok = m0 ? v1.chr_key : v0.chr_key;
         const uint32_t poso = m0 ? clip_side_pos(v1) : clip_side_pos(v0);
         const uint8_t so = strand_of(m0 ? v1.flag : v0.flag);
-        if (cat1) { c1o = u.chr_off; c1l = u.chr_len; pos1 = posu; st1 = su; c2o = oo; c2l = ol; pos2 = poso; st2 = so; }
-        else      { c2o = u.chr_off; c2l = u.chr_len; pos2 = posu; st2 = su; c1o = oo; c1l = ol; pos1 = poso; st1 = so; }
+        if (cat1) { c1o = u.chr_off; c1l = u.chr_len; k1 = u.chr_key; pos1 = posu; st1 = su; c2o = oo; c2l = ol; k2 = ok; pos2 = poso; st2 = so; }
+        else      { c2o = u.chr_off; c2l = u.chr_len; k2 = u.chr_key; pos2 = posu; st2 = su; c1o = oo; c1l = ol; k1 = ok; pos1 = poso; st1 = so; }
     }
-    return order_and_bin<WIN>(tv, c1o, c1l, pos1, st1, c2o, c2l, pos2, st2);
+    return order_and_bin<WIN>(tv, c1o, c1l, pos1, st1, c2o, c2l, pos2, st2, k1, k2);
 }
 
 MKT_HD uint32_t dec_digits(uint32_t v) {
@@ -587,15 +601,20 @@ MKT_HD uint32_t pair_line_len(uint32_t qn_len, const Verdict& v) {
 }
 // The ten decimal digits of v as ASCII, most significant first, zero padded, in two little-endian
 // words (hi8: text bytes 0..7, lo2: text bytes 8..9).  Straight-line: no data-dependent branches.
+// four decimal digits of x < 10000 as bytes, most significant digit in byte 0 (24-bit multiplies: full rate)
+MKT_HD uint32_t dig4(uint32_t x) {
+    const uint32_t hi = mul24(x, 5243u) >> 19, lo = x - mul24(hi, 100u);           // x / 100, x % 100 (exact below 10000)
+    const uint32_t th = mul24(hi, 103u) >> 10, tl = mul24(lo, 103u) >> 10;         // y / 10 (exact below 100)
+    return th | ((hi - mul24(th, 10u)) << 8) | (tl << 16) | ((lo - mul24(tl, 10u)) << 24);
+}
 MKT_HD void dec10(uint32_t v, uint64_t& hi8, uint32_t& lo2) {
-    uint32_t d[10];
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-    for (int k = 9; k >= 0; --k) { const uint32_t q = v / 10u; d[k] = v - q * 10u; v = q; }
-    hi8 = 0x3030303030303030ull | (uint64_t)d[0] | ((uint64_t)d[1] << 8) | ((uint64_t)d[2] << 16) | ((uint64_t)d[3] << 24) |
-          ((uint64_t)d[4] << 32) | ((uint64_t)d[5] << 40) | ((uint64_t)d[6] << 48) | ((uint64_t)d[7] << 56);
-    lo2 = 0x3030u | d[8] | (d[9] << 8);
+    const uint32_t a = v / 100000000u, r = v - a * 100000000u;                     // a <= 42
+    const uint32_t b = r / 10000u, c = r - b * 10000u;
+    // text: a (2 digits) b (4) c (4)
+    const uint32_t ta = mul24(a, 103u) >> 10;
+    const uint32_t d01 = ta | ((a - mul24(ta, 10u)) << 8), db = dig4(b), dc = dig4(c);
+    hi8 = 0x3030303030303030ull | (uint64_t)d01 | ((uint64_t)db << 16) | ((uint64_t)(dc & 0xFFFFu) << 48);
+    lo2 = 0x3030u | (dc >> 16);
 }
 // "<v in decimal><tail bytes>" as little-endian text in two words; tail holds ntail (<= 5) bytes.
 MKT_HD void dec_lit(uint32_t v, uint32_t ndig, uint64_t tail, uint64_t& w0, uint64_t& w1) {

@@ -20,15 +20,42 @@
 
 namespace mkt {
 
-// Geometries of the production lean kernel (tests/host/tile_emul.cpp emulates them as configs 0/10, 5/15, 4/14).
-// Bigger tiles amortise the per-tile phases better and fill more lanes per phase, but the line table of a window is
-// bounded by LDS (~193 B per line): the 48 KiB tile fits lines of >= 330 B on average (150 bp reads), the 32 KiB one
-// >= 240 B (100 bp), the 16 KiB one >= 125 B (50 bp).  Under MKT_TILES_AUTO the host starts with the biggest and
-// steps down when a block leaves more than one tile in eight to the generic kernel.
+// Capacities of the production lean kernel: a window (tile + halos) of up to kLeanTile + kLeanHB + kLeanHF bytes and kLeanLCAP
+// lines (LDS: ~226 B per line).  The BYTES per tile are chosen per input at run time (TileDims, lean_dims below): the phases
+// run one lane per line on two of the four waves, so a window should hold just under 128 lines whatever the read length; a
+// window with more lines than kLeanLCAP is left to the generic kernel.  tests/host/tile_emul.cpp emulates fixed geometries
+// (configs 0/10, 5/15, 4/14).
+#if defined(MKT_LEAN_GEOM)        // experiment builds only (microcket_amd.build.build_variant): -DMKT_LEAN_GEOM=tile,back,forward,lines
+constexpr int kLeanGeom[4] = {MKT_LEAN_GEOM};
+constexpr int kLeanTile = kLeanGeom[0], kLeanHB = kLeanGeom[1], kLeanHF = kLeanGeom[2], kLeanLCAP = kLeanGeom[3];
+#else
 constexpr int kLeanTile = 49152, kLeanHB = 3072, kLeanHF = 3072, kLeanLCAP = 168;
-constexpr int kMidTile = 32768, kMidHB = 2048, kMidHF = 3072, kMidLCAP = 160;
+#endif
+constexpr int kMidTile = 32768, kMidHB = 2048, kMidHF = 3072, kMidLCAP = 160;            // (emulation configs)
 constexpr int kDenseTile = 16384, kDenseHB = 1024, kDenseHF = 2048, kDenseLCAP = 160;
-constexpr int kWaveTile = 16384, kWaveHB = 2048, kWaveHF = 3072, kWaveLCAP = 64, kWaveGCAP = 40;      // one wave per tile
+constexpr int kLeanLinesTarget = 126;      // lines per window the host aims at: measured 122 / 126 / 129 / 132 -> 0.838 / 0.819 / 0.819 / 0.868 ms per block at 150 bp (fewer tiles against more windows past 128 lines)
+
+// tile dimensions for text of `avg` bytes per line: ~kLeanLinesTarget lines per window, a back halo of ~5 lines (the previous
+// surviving line), a forward halo of ~7.5 lines (the rest of the last group), all within the kernel's capacities
+MKT_HD TileDims lean_dims(double avg) {
+    if (avg < 48.0) avg = 48.0;
+    if (avg > 4096.0) avg = 4096.0;
+    auto r16 = [](double x) { return ((uint32_t)x + 15u) & ~15u; };
+    TileDims d;
+    d.hb = r16(5.0 * avg); d.hf = r16(7.5 * avg);
+    if (d.hb < 256u) d.hb = 256u;
+    if (d.hb > (uint32_t)kLeanHB) d.hb = (uint32_t)kLeanHB;
+    if (d.hf < 512u) d.hf = 512u;
+    if (d.hf > (uint32_t)kLeanHF) d.hf = (uint32_t)kLeanHF;
+    const double w = (double)kLeanLinesTarget * avg;
+    uint32_t t = w > (double)(d.hb + d.hf + 2048u) ? r16(w - (double)(d.hb + d.hf)) : 2048u;
+    if (t > (uint32_t)kLeanTile) t = (uint32_t)kLeanTile;
+    // the whole window a multiple of 1 KiB (64 vectors of 16 bytes, one ballot word: the scan of a full window needs no bounds)
+    const uint32_t rem = (d.hb + t + d.hf) & 1023u;
+    if (rem >= 512u && t + (1024u - rem) <= (uint32_t)kLeanTile) t += 1024u - rem; else t -= rem;
+    d.tile = t;
+    return d;
+}
 
 template <int TILE_, int HB_, int HF_, int LCAP_, int GCAP_ = 96>
 struct FastCfg {
@@ -93,16 +120,7 @@ struct FastState {
     uint32_t region_pair0, region_sam0, region_id;
 };
 
-template <class Cfg> MKT_HD TileGeom fast_geom(uint32_t tile, uint32_t n) {
-    TileGeom G;
-    uint64_t t0 = (uint64_t)tile * Cfg::TILE, t1 = t0 + Cfg::TILE;
-    G.t0 = (uint32_t)t0;
-    G.t1 = t1 < n ? (uint32_t)t1 : n;
-    G.w0 = G.t0 >= (uint32_t)Cfg::HB ? G.t0 - Cfg::HB : 0u;
-    uint64_t w1 = (uint64_t)G.t1 + Cfg::HF;
-    G.w1 = w1 < n ? (uint32_t)w1 : n;
-    return G;
-}
+template <class Cfg> MKT_HD TileGeom fast_geom(uint32_t tile, uint32_t n) { return tile_geom(tile, n, cfg_dims<Cfg>()); }
 template <class Cfg> MKT_HD TextView fast_view(const FastState<Cfg>& st, const uint8_t* text, uint32_t n, const TileGeom& G) {
     TextView tv;
     (void)G;                                          // text offsets of the lean path are head-store offsets
@@ -175,14 +193,13 @@ template <class Cfg> MKT_HD uint32_t fast_row_start(const FastState<Cfg>& st, co
     if (i == 0u && G.w0 == 0u) return 0u;
     const uint32_t* row = reinterpret_cast<const uint32_t*>(&st.win[mul24(i, (uint32_t)Cfg::HSTRIDE)]);
     const uint32_t f0 = nl_flags_exact(row[0]), f1 = nl_flags_exact(row[1]), f2 = nl_flags_exact(row[2]), f3 = nl_flags_exact(row[3]);
-    // one bit per byte, byte order: flags sit at bit 7 of every byte, so dword j shifted right by (3 - j) interleaves them
-    const uint32_t m = (f0 >> 3) | (f1 >> 2) | (f2 >> 1) | f3;    // byte b of dword j -> bit 8 b + 4 + j
+    // one bit per byte (the flags sit at bit 7 of every byte; dword j shifted right by 7 - j: byte b of dword j -> bit 8 b + j)
+    const uint32_t m = (f0 >> 7) | (f1 >> 6) | (f2 >> 5) | (f3 >> 4);
     *multi = (m & (m - 1u)) != 0u;
-    const uint32_t a0 = f0 ? ctz32(f0) >> 3 : 4u, a1 = f1 ? 4u + (ctz32(f1) >> 3) : 8u, a2 = f2 ? 8u + (ctz32(f2) >> 3) : 12u,
-                   a3 = f3 ? 12u + (ctz32(f3) >> 3) : 16u;
-    const uint32_t p = f0 ? a0 : (f1 ? a1 : (f2 ? a2 : a3));       // first newline of the vector (16: none -- cannot happen)
-    return p + 1u;
+    const uint32_t p = f0 ? (ctz32(f0) >> 3) : (f1 ? 4u + (ctz32(f1) >> 3) : (f2 ? 8u + (ctz32(f2) >> 3) : 12u + (ctz32(f3 | 0x80000000u) >> 3)));
+    return p + 1u;                                                             // first newline of the vector (none: cannot happen)
 }
+
 // ---- parse line i ------------------------------------------------------------------------------
 // Straight-line record parser of the lean path (every lane of a wave runs the same few hundred instructions; the generic
 // parsers of mkt_core.h loop per byte / per token with trip counts that differ from lane to lane).
@@ -254,36 +271,74 @@ MKT_HD bool lean_eq(const TextView& tv, uint32_t a, uint32_t b, uint32_t len) {
     return acc == 0u;
 }
 
+// One CIGAR operation on the walk state, as CigarWalk::op but as selects instead of branches (the lanes of a wave meet
+// all operation types at once).  pairutil.h:63-126.
+struct LeanCigar {
+    int32_t index, cur, lastRight;
+    bool bad;
+};
+MKT_HD void lean_cigar_op(Rec& r, LeanCigar& w, uint32_t c, int32_t v, bool last) {
+    const bool hs = c == 'H' || c == 'S', m = c == 'M', d = c == 'D', n = c == 'N', known = hs || m || d || n || c == 'I';
+    const bool live = !w.bad;
+    const bool first = w.index == 0;
+    if (live && (!known || (hs && !last && !first))) w.bad = true;
+    const bool go = live && !w.bad;
+    const bool md = go && (m || d), nn = go && n;
+    if (go && hs && last) r.rclip = v;
+    if (go && hs && !last && first) r.lclip = v;
+    if (go && m) r.mappable += v;
+    w.cur += (md || nn) ? v : 0;
+    w.lastRight = md ? w.cur - 1 : (nn ? 0 : w.lastRight);
+    if (md && first) r.right0 = w.lastRight;
+    if (md && w.index == 1) r.right1 = w.lastRight;
+    if (nn && first) { r.left1 = w.cur; r.right1 = 0; }
+    w.index += nn ? 1 : 0;
+}
+
 // Parses the record whose line starts at head-store offset `off`: sp0 / sp1 = separator bits of its bytes 0..63 / 64..127
 // (zero beyond the `room` head bytes of the line), reach = bytes from the line start to the end of the block.
 MKT_HD int parse_record_lean(const TextView& tv, uint32_t off, const Params& P, Rec& r, uint64_t sp0, uint64_t sp1, uint32_t reach) {
     // a line without its newline at the very end of the block ends at `reach`
     if (reach < 64u) sp0 |= 1ull << reach; else if (reach < 128u) sp1 |= 1ull << (reach - 64u);
+    // the first six separators.  The first one (end of the QNAME) from the first word; the other five from the 64 bytes behind
+    // it, all in one word (FLAG .. CIGAR of a lean line are shorter than that; a line that is not takes the LONG way out)
     uint32_t p[6];
+    if (sp0 == 0ull) return LP_LONG;
+    p[0] = ctz64(sp0);
+    if (p[0] >= 63u) return LP_LONG;
+    const uint32_t b0 = p[0] + 1u;                                              // 1 .. 63
+    uint64_t rest = (sp0 >> b0) | (sp1 << (64u - b0));
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 6; ++k) {                                               // the first six separators
-        if (sp0) { p[k] = ctz64(sp0); sp0 &= sp0 - 1ull; }
-        else if (sp1) { p[k] = 64u + ctz64(sp1); sp1 &= sp1 - 1ull; }
-        else p[k] = 0xFFFFu;
+    for (int k = 1; k < 6; ++k) {
+        p[k] = rest ? b0 + ctz64(rest) : 0xFFFFu;
+        rest &= rest - 1ull;
     }
-    uint8_t c[6];
+    uint32_t c[6];
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < 6; ++k) c[k] = p[k] != 0xFFFFu ? tv.win[off + p[k]] : (uint8_t)0;
-    uint32_t prev = 0xFFFFFFFFu;                                                // separator in front of the token (-1: line start)
+    for (int k = 0; k < 6; ++k) c[k] = tv.win[off + (p[k] == 0xFFFFu ? 0u : p[k])];      // (none: the line's first byte, ignored below)
+    // the first thing that is not "a token, then one tab": bit k of the masks <-> separator k
+    uint32_t miss = 0, adj = 0, nl = 0, odd = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
     for (int k = 0; k < 6; ++k) {
-        if (p[k] == 0xFFFFu) return LP_LONG;                                    // the head ends before the sixth token does
-        const bool nl = p[k] == reach || c[k] == '\n';
-        if (p[k] == prev + 1u) return nl ? LP_NOREC : LP_ODD;                    // empty token: end of a short line, or a run of separators
-        if (nl) { if (k < 5) return LP_NOREC; break; }                         // a complete line with fewer than six tokens is no record
-        if (c[k] != '\t') return LP_ODD;
-        prev = p[k];
+        const uint32_t prev = k ? p[k - 1] + 1u : 0u;
+        miss |= (p[k] == 0xFFFFu ? 1u : 0u) << k;
+        adj |= (p[k] == prev ? 1u : 0u) << k;
+        nl |= ((p[k] == reach || c[k] == '\n') ? 1u : 0u) << k;
+        odd |= (c[k] != '\t' ? 1u : 0u) << k;
+    }
+    const uint32_t ev = (miss | adj | nl | odd) & 0x3Fu;
+    if (ev) {
+        const uint32_t f = 1u << ctz32(ev);
+        if (miss & f) return LP_LONG;                                           // the head (or the 64-byte reach behind the QNAME) ends before the sixth token does
+        if (adj & f) return (nl & f) ? LP_NOREC : LP_ODD;                        // empty token: end of a short line, or a run of separators
+        if (nl & f) { if (f != 32u) return LP_NOREC; }                          // a complete line with fewer than six tokens is no record
+        else return LP_ODD;                                                     // a separator that is no tab
     }
     bool ok = tv.win[off] != '@';
     r.qn_off = 0; r.qn_len = p[0];
@@ -300,40 +355,38 @@ MKT_HD int parse_record_lean(const TextView& tv, uint32_t off, const Params& P, 
     if (mq_len <= 4u) r.mapq = lean_uint4(tv, off + p[3] + 1u, mq_len, ok);
     else if (mq_len > 10u) { ok = false; r.mapq = 0; }
     else r.mapq = lean_uint12(tv, off + p[4], mq_len, ok);                      // (p[4] > p[3] >= 12)
-    CigarWalk cw;
-    cw.begin(r);
+    // CIGAR, per OPERATION: bit i of `dig` <-> byte i of the token is a decimal digit; every other byte is an operation whose
+    // count is the digit run in front of it (up to four digits: the four bytes in front of the operation as one dword; longer
+    // runs -- the intron of a spliced alignment -- as the twelve bytes in front of it)
     const uint32_t cs = off + p[4] + 1u, clen = p[5] - p[4] - 1u;
-    // Per OPERATION instead of per byte when the token is short and every count has at most three digits (reads below
-    // 1000 bp): bit i of `dig` <-> byte i of the token is a decimal digit; each non-digit is an operation whose count is
-    // the digit run before it, read together with the operation byte as one unaligned dword.
+    if (clen > 32u || p[4] < 12u) return LP_ODD;
     uint32_t dig = 0;
-    if (clen <= 12u) {
-        dig = digit_bits4(win_load4(tv, cs));
-        if (clen > 4u) dig |= digit_bits4(win_load4(tv, cs + 4u)) << 4;
-        if (clen > 8u) dig |= digit_bits4(win_load4(tv, cs + 8u)) << 8;
-        dig &= (1u << clen) - 1u;
+    for (uint32_t k = 0; k < clen; k += 4u) dig |= digit_bits4(win_load4(tv, cs + k)) << k;
+    const uint32_t cmask = clen >= 32u ? 0xFFFFFFFFu : ((1u << clen) - 1u);
+    uint32_t ops = ~dig & cmask;
+    LeanCigar w;
+    w.index = 0; w.cur = (int32_t)r.pos; w.lastRight = 0; w.bad = false;
+    r.left0 = (int32_t)r.pos;
+    uint32_t run0 = 0;                                              // first byte of the digit run before the next operation
+    bool odd_count = false;
+    while (ops) {
+        const uint32_t q = ctz32(ops);
+        ops &= ops - 1u;
+        const uint32_t L = q - run0;                                // digits of the count
+        bool vok = true;
+        uint32_t value;
+        if (L <= 4u) {
+            const uint32_t sh = 8u * (4u - L);                      // bytes q-4 .. q-1, the run right aligned, '0' in front of it
+            const uint32_t x = win_load4(tv, cs + q - 4u);
+            value = L ? dec4((x & ~((1u << sh) - 1u)) | (0x30303030u & ((1u << sh) - 1u)), vok) : 0u;
+        } else if (L <= 9u) value = lean_uint12(tv, cs + q, L, vok);
+        else { value = 0; odd_count = true; }                      // (ten digits and more overflow the reference's int)
+        lean_cigar_op(r, w, tv.win[cs + q], (int32_t)value, q + 1u == clen);
+        run0 = q + 1u;
     }
-    if (clen <= 12u && !(dig & (dig >> 1) & (dig >> 2) & (dig >> 3))) {
-        uint32_t ops = ~dig & ((1u << clen) - 1u);
-        uint32_t run0 = 0;                                          // first byte of the digit run before the next operation
-        while (ops) {
-            const uint32_t q = ctz32(ops);
-            ops &= ops - 1u;
-            const uint32_t L = q - run0;                            // 0..3 digits
-            const uint32_t w = win_load4(tv, cs + q - 3u);          // bytes q-3 .. q: hundreds, tens, units, operation
-            const int32_t value = (int32_t)((L > 0u ? (w >> 16) & 15u : 0u) + (L > 1u ? mul24((w >> 8) & 15u, 10u) : 0u) + (L > 2u ? mul24(w & 15u, 100u) : 0u));
-            cw.value = value;
-            cw.op(r, (uint8_t)(w >> 24), q + 1u == clen);
-            run0 = q + 1u;
-        }
-    } else {
-        for (uint32_t i = 0; i < clen; i += 4u) {
-            uint32_t w = win_load4(tv, cs + i);
-            const uint32_t m = clen - i < 4u ? clen - i : 4u;
-            for (uint32_t b = 0; b < m; ++b) { cw.step(r, (uint8_t)(w & 0xFFu), i + b + 1u == clen); w >>= 8; }
-        }
-    }
-    cw.end(r);
+    if (odd_count) return LP_ODD;
+    // (digits behind the last operation: the reference leaves them in `value` and ignores them)
+    if (!w.bad && w.lastRight != 0) { r.segCnt = w.index + 1; r.rightLast = w.lastRight; }
     r.survive = ok && !(r.flag & 0x700u) && r.mapq >= P.min_mapq;
     return LP_OK;
 }
@@ -443,6 +496,21 @@ template <class Cfg> MKT_HD Seg fast_seg(const FastState<Cfg>& st, uint32_t idx)
     s.rightLast = s.segCnt == 2 ? s.right1 : s.right0;
     s.flag = st.flag[idx]; s.pos = st.rc.f.pos[idx];
     s.chr_off = (uint32_t)st.off16[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];      // head-store offset
+    {   // the first eight name bytes, big endian, zero padded
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(st.win);
+        const uint32_t k = s.chr_off >> 2, sh = s.chr_off & 3u;
+        const uint32_t q0 = w[k], q1 = w[k + 1], q2 = w[k + 2];
+        uint32_t x0, x1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        x0 = __builtin_amdgcn_alignbyte(q1, q0, sh); x1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
+#else
+        x0 = sh ? ((q0 >> (8u * sh)) | (q1 << (32u - 8u * sh))) : q0; x1 = sh ? ((q1 >> (8u * sh)) | (q2 << (32u - 8u * sh))) : q1;
+#endif
+        const uint32_t n = s.chr_len;
+        if (n < 4u) { x0 &= (1u << (8u * n)) - 1u; x1 = 0; }
+        else if (n < 8u) x1 &= (1u << (8u * (n - 4u))) - 1u;
+        s.chr_key = ((uint64_t)bswap32(x0) << 32) | bswap32(x1);
+    }
     return s;
 }
 

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
         const uint32_t t = s_tile;
         if (t >= a.ntiles) break;
         STAMP(0);
-        const TileGeom G = tile_geom<Cfg>(t, n);
+        const TileGeom G = tile_geom(t, n, a.dims);             // (window <= Cfg::W: the launcher checks)
         const uint32_t wlen = G.w1 - G.w0;
         const uint32_t nvec = (wlen + 15u) >> 4;
         const TextView tv = tile_view(st, a.text, n, G);
@@ -434,13 +434,81 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 // NTW threads per workgroup; RR waves share the group phase of a tile (lines dealt round-robin: 2 beats 1, 3 and 4 at
 // 48 KiB tiles); WPS = waves per SIMD the kernel is compiled for (profiles/r02_kernel_variants.txt has the measurements
 // behind these choices and behind the variants that are gone from the source).
-constexpr int kLoadBatch = 14;     // 16-byte window vectors of a lane in flight at once
+// Newline scan of (a part of) tile tt's window by nws waves: wave slot ws (0 .. nws-1) takes the 64-vector groups k * nws + ws
+// for k in [kb, ke).  The text streams through registers only, up to fourteen 16-byte vectors of a lane in flight at once (a part
+// of the largest window is one batch: one memory round trip); per vector a 3-op-per-dword "some byte == '\n'" test and one
+// ballot: bit l of hit[g] <-> vector 64 g + l of the window holds a newline.
+// FULL: the window is a whole number of 64-vector groups and every group of the part lies inside it (all tiles but those at the
+// two ends of a block when hb + tile + hf is a multiple of 1024, as lean_dims() makes it): a running scalar pointer, no
+// per-lane bounds.  Otherwise groups and lanes past the window read its last group / vector again -- no branch, no exec mask,
+// no zero fill in front of the loads (a conditional load costs a wait right behind it) -- and what they read is ignored.
+constexpr int kLoadBatch = 14;
+__device__ inline uint64_t has_newline_ballot(const uint4& y, bool valid) {
+    const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
+    const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
+    return __ballot((z & 0x80808080u) != 0u && valid);
+}
+template <class Cfg, uint32_t nws>
+__device__ inline void fast_scan(const KArgs& a, uint32_t tt, uint64_t* hit, uint32_t ws_, uint32_t kb, uint32_t ke, int lane) {
+    const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws_);      // (wave-uniform: the group arithmetic below is scalar)
+    const uint32_t n = a.n;
+    const TileGeom G = tile_geom(tt, n, a.dims);
+    const uint32_t wlen = G.w1 - G.w0, nvec = (wlen + 15u) >> 4;
+    const uint8_t* wbase = a.text + G.w0;
+    const uint32_t loff = (uint32_t)lane << 4;
+    const uint32_t ngr = nvec >> 6;                                            // whole groups of the window
+    if (!(wlen & 1023u) && kb < ke && (ke - 1u) * nws + ws < ngr && ke - kb <= (uint32_t)kLoadBatch) {
+        const uint32_t cnt = ke - kb, stride = nws << 10;
+        const uint8_t* p0 = wbase + ((size_t)(kb * nws + ws) << 10);
+        uint4 x[kLoadBatch];
+#pragma unroll
+        for (int k = 0; k < kLoadBatch; ++k) {         // (past the part's last group: that group again)
+            const uint32_t kk = (uint32_t)k < cnt ? (uint32_t)k : cnt - 1u;
+            x[k] = *reinterpret_cast<const uint4*>(p0 + (size_t)kk * stride + loff);
+        }
+#pragma unroll
+        for (int k = 0; k < kLoadBatch; ++k) {
+            if ((uint32_t)k < cnt) {                   // (no break: the array must stay in registers, every index a constant)
+                const uint64_t bm = has_newline_ballot(x[k], true);
+                const uint32_t g = (kb + (uint32_t)k) * nws + ws;
+                if (lane == 0 && g < (uint32_t)Cfg::HMW) hit[g] = bm;
+            }
+        }
+        return;
+    }
+    const uint32_t tail = (G.w1 >= n) ? (wlen & 15u) : 0u;      // bytes of a partial last vector (only the block's last window has one)
+    for (uint32_t k0 = kb; k0 < ke; k0 += kLoadBatch) {
+        uint4 x[kLoadBatch];
+#pragma unroll
+        for (int k = 0; k < kLoadBatch; ++k) {         // all loads of the batch first ...
+            // (the text buffer is readable up to the next multiple of 16: include/mkt.h)
+            const uint32_t g0 = (k0 + k) * nws + ws, glast = (nvec - 1u) >> 6, g = g0 < glast ? g0 : glast;
+            const uint32_t lim = nvec - (g << 6), l = (uint32_t)lane < lim ? (uint32_t)lane : lim - 1u;
+            x[k] = *reinterpret_cast<const uint4*>(wbase + ((size_t)g << 10) + (l << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < kLoadBatch; ++k) {         // ... then the math
+            const uint32_t g = (k0 + k) * nws + ws;
+            if (k0 + k >= ke || (g << 6) >= nvec) continue;
+            uint4 y = x[k];
+            if (tail && (g << 6) + 64u >= nvec && (g << 6) + (uint32_t)lane == nvec - 1u) {      // bytes past the end of the block are not text
+                uint32_t* w = reinterpret_cast<uint32_t*>(&y);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t lo = (uint32_t)d * 4u;
+                    w[d] = tail >= lo + 4u ? w[d] : (tail > lo ? (w[d] & ((1u << ((tail - lo) * 8u)) - 1u)) : 0u);
+                }
+            }
+            const uint64_t bm = has_newline_ballot(y, (uint32_t)lane < nvec - (g << 6));
+            if (lane == 0 && g < (uint32_t)Cfg::HMW) hit[g] = bm;
+        }
+    }
+}
 
 template <class Cfg, int NTW, int RR, int WPS>
 __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
     __shared__ FastState<Cfg> st;
     __shared__ ScanScratch scan;
-    constexpr int NVEC = (Cfg::W + 15) / 16;
     static_assert(Cfg::LCAP <= NTW, "one line per thread in the sums");
     static_assert(NTW % 64 == 0 && NTW <= NT && RR * 64 <= NTW, "whole waves");
     const int tid0 = threadIdx.x;
@@ -451,6 +519,16 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
     STAMP_DECL();
 
     __shared__ uint32_t wg_cnt[C_COUNT];                  // this workgroup's share of the block's counters
+    // Newline bitmaps of two windows: while waves 0 and 1 parse and classify tile t, the waves that have nothing to do in those
+    // phases (NSW of them, the last ones) scan the window of the workgroup's NEXT tile into the other bitmap
+    __shared__ uint64_t s_hit[2][Cfg::HMW + 1];
+    constexpr int NWV = NTW / 64;
+    constexpr int NSW = NWV >= 4 ? 2 : 0;                 // scanning waves of the pipeline (0: every tile is scanned by all waves at its start)
+    // 64-vector groups of a full window: per wave when all waves scan / per scanning wave of the pipeline, in two parts
+    const uint32_t ngrp = (a.dims.hb + a.dims.tile + a.dims.hf + 1023u) >> 10;
+    const uint32_t lpt_all = (ngrp + NWV - 1) / NWV, lpt_sw = NSW ? (ngrp + NSW - 1) / NSW : 0u, lpt_a = (lpt_sw + 1u) >> 1;
+    // (a wave whose last group would lie past a full window stops one short: ngrp need not be a multiple of the wave count)
+    auto own = [&](uint32_t ws, uint32_t nws, uint32_t ke) { const uint32_t c = ws < ngrp ? (ngrp - ws + nws - 1u) / nws : 0u; return ke < c ? ke : c; };
     if (tid0 < (int)C_COUNT) wg_cnt[tid0] = 0;
     fast_init(st, (uint32_t)tid0);
     // static tile assignment: no ticket atomic (30 k tiles per block would saturate one address)
@@ -459,6 +537,8 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
     if (tid0 == 0) s_out = a.out;
     uint32_t gdim = gridDim.x;                                   // (read once: the dispatch packet is a scalar memory load away)
     asm volatile("" : "+s"(gdim));
+    uint32_t cur = 0;                                             // bitmap of the current tile
+    bool scanned = false;                                         // ... already filled by the previous iteration
     for (uint32_t t = blockIdx.x; t < a.ntiles; t += gdim) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                   // per-lane addresses are recomputed per tile, not kept live (and spilled) across the loop
@@ -466,48 +546,15 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
         // that ends the scan phase)
         if (tid == 0) fast_reset(st);
         STAMP(0);
-        const TileGeom G = fast_geom<Cfg>(t, n);
-        const uint32_t wlen = G.w1 - G.w0;
-        const uint32_t nvec = (wlen + 15u) >> 4;
+        const TileGeom G = tile_geom(t, n, a.dims);             // (window <= Cfg::W: the launcher checks)
         const TextView tv = fast_view(st, a.text, n, G);
 
-        // ---- scan: which 16-byte vectors of the window hold a newline.  The text streams through registers only; per vector
-        //      a 3-op-per-dword "some byte == '\n'" test and one ballot: 64 vectors per bitmap word, in window order.
-        {
-            constexpr int LPT = (NVEC + NTW - 1) / NTW;        // 16-byte vectors per thread
-            constexpr int BATCH = LPT < kLoadBatch ? LPT : kLoadBatch;
-            const uint32_t tail = (G.w1 >= n) ? (wlen & 15u) : 0u;      // bytes of a partial last vector (only the block's last window has one)
-            const int wv = tid >> 6, lane = tid & 63;
-#pragma unroll
-            for (int k0 = 0; k0 < LPT; k0 += BATCH) {
-                uint4 x[BATCH];
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {              // all loads of the batch first ...
-                    const uint32_t v = tid + (k0 + k) * NTW;
-                    x[k] = make_uint4(0, 0, 0, 0);
-                    // the text buffer is readable up to the next multiple of 16 (include/mkt.h)
-                    if (k0 + k < LPT && v < nvec) x[k] = *reinterpret_cast<const uint4*>(a.text + G.w0 + (v << 4));
-                }
-#pragma unroll
-                for (int k = 0; k < BATCH; ++k) {              // ... then the math
-                    if (k0 + k >= LPT) continue;
-                    const uint32_t v = tid + (k0 + k) * NTW;
-                    uint4 y = x[k];
-                    if (tail && v == nvec - 1u) {              // bytes past the end of the block are not text
-                        uint32_t* w = reinterpret_cast<uint32_t*>(&y);
-#pragma unroll
-                        for (int d = 0; d < 4; ++d) {
-                            const uint32_t lo = (uint32_t)d * 4u;
-                            w[d] = tail >= lo + 4u ? w[d] : (tail > lo ? (w[d] & ((1u << ((tail - lo) * 8u)) - 1u)) : 0u);
-                        }
-                    }
-                    const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
-                    const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
-                    const uint64_t bm = __ballot((z & 0x80808080u) != 0u);
-                    if (lane == 0 && (uint32_t)((k0 + k) * (NTW / 64) + wv) < (uint32_t)Cfg::HMW) st.u.m.hitmap[(k0 + k) * (NTW / 64) + wv] = bm;
-                }
-            }
-        }
+        // ---- scan: which 16-byte vectors of the window hold a newline (the workgroup's first tile, and every tile of a build
+        //      without the pipeline: all waves; afterwards the bitmap is there already)
+        // (the wave number as a SCALAR: a wave that does not scan must branch around the scan's scalar code, not run it with EXEC = 0)
+        const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+        if (!scanned) fast_scan<Cfg, NWV>(a, t, s_hit[cur], wave, 0u, own(wave, NWV, lpt_all), tid & 63);
+        scanned = false;
         __syncthreads();
         STAMP(1);
         STOP_AFTER(1)
@@ -515,7 +562,7 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
         // ---- line table: one entry per newline vector, in window order (one wave; a bitmap word per lane)
         if (tid < 64) {
             static_assert(Cfg::HMW <= 64, "one bitmap word per lane of one wave");
-            uint64_t m = tid < Cfg::HMW ? st.u.m.hitmap[tid] : 0ull;
+            uint64_t m = (uint32_t)tid < ((G.w1 - G.w0 + 1023u) >> 10) ? s_hit[cur][tid] : 0ull;      // (words past the window hold other tiles' bits)
             const uint32_t cnt = (uint32_t)__popcll(m);
             const uint32_t inc = wave_iscan32(cnt);
             const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
@@ -613,6 +660,9 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
             }
             if (NTW < 256 && tid < 4 && tid >= NTW / 64) { st.m_surv[tid] = 0; st.m_eqp[tid] = 0; st.m_r1[tid] = 0; st.m_r2[tid] = 0; st.m_start[tid] = 0; }
         }
+        // the scanning waves: first half of the next tile's window (behind their own few lines, if the window has more than 128)
+        if (NSW && wave >= (uint32_t)(NWV - NSW) && t + gdim < a.ntiles)
+            fast_scan<Cfg, (NSW ? NSW : 1)>(a, t + gdim, s_hit[cur ^ 1u], wave - (uint32_t)(NWV - NSW), 0u, own(wave - (uint32_t)(NWV - NSW), NSW, lpt_a), tid & 63);
         __syncthreads();
         STAMP(3);
         STOP_AFTER(3)
@@ -629,6 +679,10 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
         __syncthreads();
         STAMP(10);
         if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * RR) fast_group(st, tv, P, G, i);
+        // the scanning waves: the rest of the next tile's window
+        if (NSW && wave >= (uint32_t)(NWV - NSW) && t + gdim < a.ntiles)
+            fast_scan<Cfg, (NSW ? NSW : 1)>(a, t + gdim, s_hit[cur ^ 1u], wave - (uint32_t)(NWV - NSW), lpt_a, own(wave - (uint32_t)(NWV - NSW), NSW, lpt_sw), tid & 63);
+        if (NSW && t + gdim < a.ntiles) { scanned = true; cur ^= 1u; }
         __syncthreads();
         STAMP(4);
         STOP_AFTER(4)
@@ -986,39 +1040,45 @@ hipError_t launch_sc_logged(const uint64_t* list, uint64_t n, uint64_t drop_grou
 }
 
 // ---------------------------------------------------------------------------------------------
-typedef FastCfg<kLeanTile, kLeanHB, kLeanHF, kLeanLCAP> CfgLean;
-typedef TileCfg<kLeanTile, kLeanHB, kLeanHF, 512, 4> CfgFast;                 // same tile index space as the lean kernel
-typedef TileCfg<kMidTile, kMidHB, kMidHF, 512, 4> CfgMid;                    // ... and as its variants for shorter lines
-typedef TileCfg<kDenseTile, kDenseHB, kDenseHF, 256, 4> CfgDense;
+typedef FastCfg<kLeanTile, kLeanHB, kLeanHF, kLeanLCAP> CfgLean;               // capacities of the lean kernel
+typedef TileCfg<kLeanTile, kLeanHB, kLeanHF, 512, 4> CfgFast;                 // ... and of the generic kernel that takes what it defers
 typedef TileCfg<256, 64, 192, 512, 4> CfgSmall;
-typedef FastCfg<kMidTile, kMidHB, kMidHF, kMidLCAP> CfgLeanMid;
-typedef FastCfg<kDenseTile, kDenseHB, kDenseHF, kDenseLCAP> CfgLeanDense;
-// one WAVE per tile (a workgroup of 64 threads: its barriers are no-ops, every wave of the CU runs on its own)
-typedef FastCfg<kWaveTile, kWaveHB, kWaveHF, kWaveLCAP, kWaveGCAP> CfgLeanWave;
-typedef TileCfg<kWaveTile, kWaveHB, kWaveHF, 256, 4> CfgWave;
 
-uint32_t tile_bytes(int cfg) {
-    return cfg == CFG_SMALL ? CfgSmall::TILE : (cfg == CFG_DENSE ? CfgDense::TILE : (cfg == CFG_MID ? CfgMid::TILE : (cfg == CFG_WAVE ? CfgWave::TILE : CfgFast::TILE)));
+TileDims small_dims() { return cfg_dims<CfgSmall>(); }
+TileDims max_dims() { return cfg_dims<CfgLean>(); }
+static bool dims_ok(const TileDims& d, const TileDims& mx) {
+    return d.tile >= 16u && !((d.tile | d.hb | d.hf) & 15u) && d.tile <= mx.tile && d.hb <= mx.hb && d.hf <= mx.hf;
 }
 
-// 4 workgroups of 256 threads per CU (k_fast is compiled for 4 waves per SIMD); wave-wide workgroups: as many as the LDS admits
-uint32_t fast_max_workgroups(int cfg) { return cfg == CFG_WAVE ? 256u * (uint32_t)(160 * 1024 / (sizeof(FastState<CfgLeanWave>) + 512)) : 256u * 4u; }
+uint32_t fast_max_workgroups(int) { return 256u * 4u; }      // 4 workgroups of 256 threads per CU (k_fast is compiled for 4 waves per SIMD)
 
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
+    if (!dims_ok(a.dims, cfg == CFG_SMALL ? small_dims() : max_dims())) return hipErrorInvalidValue;
     if (cfg == CFG_SMALL) hipLaunchKernelGGL(k_tiles<CfgSmall>, dim3(grid), dim3(NT), 0, s, a);
-    else if (cfg == CFG_DENSE) hipLaunchKernelGGL(k_tiles<CfgDense>, dim3(grid), dim3(NT), 0, s, a);
-    else if (cfg == CFG_MID) hipLaunchKernelGGL(k_tiles<CfgMid>, dim3(grid), dim3(NT), 0, s, a);
-    else if (cfg == CFG_WAVE) hipLaunchKernelGGL(k_tiles<CfgWave>, dim3(grid), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL(k_tiles<CfgFast>, dim3(grid), dim3(NT), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s) {
+hipError_t launch_fast(const KArgs& a, int, int grid, hipStream_t s) {
     if (a.ntiles == 0) return hipSuccess;
-    if (cfg == CFG_DENSE) hipLaunchKernelGGL((k_fast<CfgLeanDense, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
-    else if (cfg == CFG_MID) hipLaunchKernelGGL((k_fast<CfgLeanMid, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
-    else if (cfg == CFG_WAVE) hipLaunchKernelGGL((k_fast<CfgLeanWave, 64, 1, 2>), dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL((k_fast<CfgLean, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
+    if (!dims_ok(a.dims, max_dims())) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_fast<CfgLean, NT, 2, 4>), dim3(grid), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+// line-length probe: newlines in the first bytes of device-resident text
+__global__ void k_count_nl(const uint8_t* text, size_t n, unsigned long long* out) {
+    unsigned long long mine = 0;
+    const size_t nv = n >> 4;
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) {
+        const uint4 x = reinterpret_cast<const uint4*>(text)[v];
+        mine += __popc(nl_flags(x.x)) + __popc(nl_flags(x.y)) + __popc(nl_flags(x.z)) + __popc(nl_flags(x.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (size_t b = nv << 4; b < n; ++b) mine += text[b] == '\n';
+    for (int d = 32; d >= 1; d >>= 1) mine += shfl_xor64(mine, d);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+hipError_t launch_count_newlines(const uint8_t* text, size_t n, unsigned long long* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_count_nl, dim3(64), dim3(256), 0, s, text, n, out);
     return hipGetLastError();
 }
 hipError_t launch_finish(const KArgs& a, hipStream_t s) {

@@ -7,7 +7,7 @@
 
 namespace mkt {
 
-enum { CFG_FAST = 0, CFG_SMALL = 1, CFG_DENSE = 2, CFG_MID = 3, CFG_WAVE = 4 };      // tile geometries: 48 KiB lean, 256 B generic only, 16 KiB lean, 32 KiB lean, 16 KiB one wave per tile
+enum { CFG_FAST = 0, CFG_SMALL = 1 };      // kernels: lean + generic for what it defers (tile bytes chosen at run time) / generic only, 256-byte tiles
 
 // totals of the blocks a context has finished, kept on the device so that resident blocks chain
 // without a host round trip
@@ -26,6 +26,7 @@ struct KArgs {
     const uint8_t* text;        // block text, 16-byte aligned
     uint32_t n;                 // block bytes (< 2^31)
     uint32_t ntiles;
+    TileDims dims;              // bytes per tile / back halo / forward halo (multiples of 16, within the kernels' capacities)
     Params P;
     uint64_t* descA;            // per-tile look-back words: groups | emitted
     uint64_t* descB;            //                            pair_bytes | self-circles
@@ -55,8 +56,11 @@ struct KArgs {
     int32_t debug_stop;         // diagnostic builds only: leave every tile after phase k (timing ladder; outputs are wrong)
 };
 
-uint32_t tile_bytes(int cfg);
+TileDims small_dims();                       // the 256-byte tiles of CFG_SMALL
+TileDims max_dims();                         // the largest geometry the lean kernel (and the generic kernel behind it) takes
 uint32_t fast_max_workgroups(int cfg);      // grid of the lean kernel: the workgroups that are resident at once on 256 CUs
+// newlines in text[0, n): the host's line-length probe on device-resident text (one small launch; *out zeroed by the caller)
+hipError_t launch_count_newlines(const uint8_t* text, size_t n, unsigned long long* out, hipStream_t s);
 hipError_t launch_tiles(const KArgs& a, int cfg, int grid, hipStream_t s);
 hipError_t launch_fast(const KArgs& a, int cfg, int grid, hipStream_t s);
 uint32_t finish_chunk_tiles();

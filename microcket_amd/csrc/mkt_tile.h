@@ -45,17 +45,22 @@ enum ErrBits : uint32_t {
 };
 
 struct TileGeom { uint32_t t0, t1, w0, w1; };
-template <class Cfg> MKT_HD TileGeom tile_geom(uint32_t tile, uint32_t n) {
+// Tile geometry of a block, chosen per input at run time (multiples of 16 bytes): the kernels are compiled for CAPACITIES (window
+// bytes, lines per window), the host picks the bytes per tile so that a window holds about as many lines as the phases have lanes
+struct TileDims { uint32_t tile, hb, hf; };
+MKT_HD TileGeom tile_geom(uint32_t tile, uint32_t n, const TileDims& d) {
     TileGeom G;
-    uint64_t t0 = (uint64_t)tile * Cfg::TILE;
-    uint64_t t1 = t0 + Cfg::TILE;
+    uint64_t t0 = (uint64_t)tile * d.tile;
+    uint64_t t1 = t0 + d.tile;
     G.t0 = (uint32_t)t0;
     G.t1 = t1 < n ? (uint32_t)t1 : n;
-    G.w0 = G.t0 >= (uint32_t)Cfg::HB ? G.t0 - Cfg::HB : 0u;
-    uint64_t w1 = (uint64_t)G.t1 + Cfg::HF;
+    G.w0 = G.t0 >= d.hb ? G.t0 - d.hb : 0u;
+    uint64_t w1 = (uint64_t)G.t1 + d.hf;
     G.w1 = w1 < n ? (uint32_t)w1 : n;
     return G;
 }
+template <class Cfg> MKT_HD TileDims cfg_dims() { TileDims d; d.tile = (uint32_t)Cfg::TILE; d.hb = (uint32_t)Cfg::HB; d.hf = (uint32_t)Cfg::HF; return d; }
+template <class Cfg> MKT_HD TileGeom tile_geom(uint32_t tile, uint32_t n) { return tile_geom(tile, n, cfg_dims<Cfg>()); }
 MKT_HD uint32_t num_tiles(uint32_t n, uint32_t tile_bytes) { return n == 0 ? 0u : (n + tile_bytes - 1) / tile_bytes; }
 
 // line bits
@@ -166,13 +171,13 @@ template <class Cfg> MKT_HD Seg load_seg(const TileState<Cfg>& st, uint32_t idx)
     s.left0 = (int32_t)st.pos[idx]; s.left1 = st.left1[idx]; s.right0 = st.right0[idx]; s.right1 = st.right1[idx];
     s.rightLast = s.segCnt == 2 ? s.right1 : s.right0;       // right[segCnt-1]; only read when segCnt is 1 or 2
     s.flag = st.flag[idx]; s.pos = st.pos[idx];
-    s.chr_off = st.off[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx];
+    s.chr_off = st.off[idx] + st.rn_off[idx]; s.chr_len = st.rn_len[idx]; s.chr_key = 0;
     return s;
 }
 MKT_HD Seg seg_zero() {
     Seg s;
     s.segCnt = s.lclip = s.rclip = s.mappable = s.left0 = s.left1 = s.right0 = s.right1 = s.rightLast = 0;
-    s.flag = s.pos = s.chr_off = s.chr_len = 0;
+    s.flag = s.pos = s.chr_off = s.chr_len = 0; s.chr_key = 0;
     return s;
 }
 

@@ -101,3 +101,57 @@ def test_long_fields_take_the_generic_parser():
             + b"z\t65\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF\nz\t129\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF\n")
     for cfg in (0, 1, 2, 3, 4, 5, 10, 12, 13, 14, 15):
         _check(text, "unc", 4, 0.5, 10, True, cfg, 0)
+
+
+def test_cigar_shapes_lean_and_generic():
+    """CIGAR shapes the lean parser decodes per operation (counts of up to nine digits, tokens of up to 32 bytes) and those it
+    hands to the generic kernel (longer tokens, ten-digit counts), next to odd ones both must treat like the reference:
+    unknown operations, `*`, digits behind the last operation, an operation without a count, clips in the middle."""
+    cigars = [b"150M", b"60M90S", b"60H90M", b"70M1I79M", b"30M1D90M30S", b"50M1234N100M", b"50M123456789N100M", b"20S30M54321N40M10D40M20S",
+              b"10M2I10M2D10M2I10M2D10M2I10M90S", b"10M1I10M1D10M1I10M1D10M1I10M1D10M1I10M1D80S", b"50M1234567890N100M", b"*", b"150M7", b"M", b"50M5S95M",
+              b"75X75M", b"0M150M", b"100M50N", b"1000M", b"12345M", b"50M3N3N3N50M", b"5S5H140M", b"150", b"9999S1M"]
+    lines = []
+    for k, cg in enumerate(cigars):
+        for mate, (flag, pos, chrom) in enumerate(((65 + (k % 2) * 16, 1000 + 37 * k, b"chr1"), (129 + ((k // 2) % 2) * 16, 1400 + 41 * k, b"chr1" if k % 3 else b"chr10"))):
+            lines.append(b"rd%05d\t%d\t%s\t%d\t60\t%s\t=\t1\t0\tACGT\tFFFF\tNM:i:0" % (k, flag, chrom, pos, cg if mate == k % 2 else b"150M"))
+    # the same CIGARs as the split read of a 1 + 2 group
+    for k, cg in enumerate(cigars):
+        lines.append(b"sp%05d\t65\tchr2\t%d\t60\t150M\t=\t1\t0\tACGT\tFFFF" % (k, 5000 + k))
+        lines.append(b"sp%05d\t129\tchr2\t%d\t60\t%s\t=\t1\t0\tACGT\tFFFF" % (k, 5300 + k, cg))
+        lines.append(b"sp%05d\t2177\tchr3\t%d\t60\t80H70M\t=\t1\t0\tACGT\tFFFF" % (k, 900 + k))
+    lines += [b"zz\t65\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF", b"zz\t129\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF"]
+    text = b"\n".join(lines) + b"\n"
+    # without the two shapes the lean parser refuses (a token of more than 32 bytes, a ten-digit count): the lean path must take the tile
+    keep = [ln for ln in lines if b"10M1I10M1D10M1I10M1D10M1I10M1D10M1I10M1D80S" not in ln and b"1234567890N" not in ln]
+    lean_text = b"\n".join(keep) + b"\n"
+    for mode in ("unc", "flash"):
+        for cfg in (0, 1, 3, 10, 12, 14):
+            for (T, ratio, mapq, sam) in ((4, 0.5, 10, True), (2, 0.8, 0, False)):
+                _check(text, mode, T, ratio, mapq, sam, cfg, 0)
+                _check(lean_text, mode, T, ratio, mapq, sam, cfg, 0)
+        es = util.emul_run(lean_text, mode, 4, 0.5, 10, True, 10, 0)[3]
+        assert es["tiles"] == 1 and es["lean_tiles"] == 1, es
+        es = util.emul_run(text, mode, 4, 0.5, 10, True, 10, 0)[3]
+        assert es["lean_tiles"] == 0, es
+
+
+def test_chromosome_name_order_short_and_long_names():
+    """chr1.compare(chr2) is bytewise (flash2pairs.h:110, unc2pairs.h:315).  The lean path compares the first eight bytes as one
+    number and only looks further when they agree: names of 1..22 bytes with shared prefixes, both orders, both modes."""
+    names = [b"chr1", b"chr10", b"chr2", b"chrX", b"chrUn_KI270742v1", b"chrUn_KI270743v1", b"chrUn_KI2", b"chrUn_KI", b"chrUn_K", b"chr1_KI270706v1_random",
+             b"chr1_KI270707v1_random", b"chr1_KI270706v1_randon", b"1", b"10", b"MT", b"chrEBV", b"chr22_KI270731v1_random", b"c"]
+    lines = []
+    k = 0
+    for a in names:
+        for b in names:
+            q = b"pr%05d" % k
+            lines.append(q + b"\t65\t" + a + b"\t%d\t60\t100M\t=\t1\t0\t" % (1000 + k) + b"A" * 100 + b"\t" + b"F" * 100)
+            lines.append(q + b"\t145\t" + b + b"\t%d\t60\t100M\t=\t1\t0\t" % (90000 - k) + b"A" * 100 + b"\t" + b"F" * 100)
+            k += 1
+    lines += [b"zz\t65\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF", b"zz\t129\tchr1\t1\t60\t1M\t=\t1\t0\tA\tF"]
+    text = b"\n".join(lines) + b"\n"
+    for mode in ("unc", "flash"):
+        for cfg in (0, 1, 10, 14, 15):
+            _check(text, mode, 4, 0.5, 10, True, cfg, 0)
+        es = util.emul_run(text, mode, 4, 0.5, 10, True, 15, 0)[3]       # (250-byte lines: the 32 KiB lean geometry holds them)
+        assert es["lean_tiles"] == es["tiles"], es

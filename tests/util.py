@@ -199,7 +199,8 @@ def emul_run(text, mode, threads=4, ratio=0.5, mapq=10, sam=True, cfg=0, block=0
     s = C.string_at(osam, nsam.value)
     _emul.emul_free(op)
     _emul.emul_free(osam)
-    return pairs, s, log.value, {"groups": st[0], "pairs": st[1], "err": st[2], "blocks": st[3]}
+    return pairs, s, log.value, {"groups": st[0], "pairs": st[1], "err": st[2], "blocks": st[3] & 0xFFFFF, "lean_tiles": (st[3] >> 20) & 0x3FFFFF,
+                                 "tiles": st[3] >> 42}
 
 
 class EmulShard:

@@ -1,5 +1,5 @@
 """Diagnostic: k_fast launch time per tile geometry on the same resident data set, per read length.
-    python tools/geom_bench.py [--pairs N] [--read-lens 150,100,60] [--tiles fast,auto,wave] [--sam]
+    python tools/geom_bench.py [--pairs N] [--read-lens 150,100,60] [--tiles fast,auto] [--sam]
 Prints ms per launch, GB/s of text, M lines/s-equivalent pairs/s, deferred tiles; checks that every geometry gives the same
 statistics and .log (the outputs themselves are pinned by tests/test_gpu_parity.py)."""
 import argparse
@@ -14,12 +14,12 @@ from microcket_amd import capi  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", type=int, default=8_000_000)
 ap.add_argument("--read-lens", default="150,100,60")
-ap.add_argument("--tiles", default="fast,auto,wave")
+ap.add_argument("--tiles", default="fast,auto")
 ap.add_argument("--sam", action="store_true")
 ap.add_argument("--mode", default="unc")
 ap.add_argument("--passes", type=int, default=5)
 args = ap.parse_args()
-TILES = {"fast": capi.TILES_FAST, "auto": capi.TILES_AUTO, "wave": capi.TILES_WAVE}
+TILES = {"fast": capi.TILES_FAST, "auto": capi.TILES_AUTO}
 for rl in [int(x) for x in args.read_lens.split(",")]:
     ref = None
     for tn in args.tiles.split(","):

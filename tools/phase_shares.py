@@ -16,7 +16,7 @@ ORDER = [1, 2, 9, 3, 10, 4, 6, 11, 8]
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 sam = len(sys.argv) > 2 and sys.argv[2] == "yes"
-ctx = m.Context("unc", 0.5, 10, sam, 8, device=0, tiles=m.TILES_FAST)
+ctx = m.Context("unc", 0.5, 10, sam, 8, device=0, tiles=m.TILES_AUTO if os.environ.get("MKT_TILES") == "auto" else m.TILES_FAST)
 ds = ctx.dataset(20260105, 0, pairs, 1 << 19)
 ctx.L.mkt_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 16)()

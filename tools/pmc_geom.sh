@@ -1,5 +1,5 @@
 #!/bin/bash
-# Diagnostic: SQ counters of k_fast per (read length, tile geometry).  GPU box, repo root:  bash tools/pmc_geom.sh gpurun_out/pmc_geom "150:fast 100:auto 100:wave"
+# Diagnostic: SQ counters of k_fast per (read length, tile geometry).  GPU box, repo root:  bash tools/pmc_geom.sh gpurun_out/pmc_geom "150:fast 100:auto"
 set -e
 OUT=$1; R=$PWD; mkdir -p $OUT; export TMPDIR=/tmp
 cat > /tmp/pg_run.py <<PY
@@ -8,7 +8,7 @@ sys.path.insert(0, "$R")
 import microcket_amd as m
 from microcket_amd import capi
 rl, tn = int(sys.argv[1]), sys.argv[2]
-ctx = m.Context("unc", 0.5, 10, False, 8, device=0, tiles={"fast": capi.TILES_FAST, "auto": capi.TILES_AUTO, "wave": capi.TILES_WAVE}[tn])
+ctx = m.Context("unc", 0.5, 10, False, 8, device=0, tiles={"fast": capi.TILES_FAST, "auto": capi.TILES_AUTO}[tn])
 ds = ctx.dataset(20260105, 0, 4000000, 1 << 21, read_len=rl)
 for _ in range(3):
     for (p, n, g) in ds.blocks: ctx.submit_device(p, n)
