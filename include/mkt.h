@@ -254,6 +254,7 @@ typedef struct mkt_bam mkt_bam;
 int mkt_bam_create(int device, mkt_bam** out);
 void mkt_bam_destroy(mkt_bam* b);
 const char* mkt_bam_error(const mkt_bam* b);
+const char* mkt_bam_note(const mkt_bam* b);                                /* after a successful run: why no index was made ("" otherwise) */
 int mkt_bam_add(mkt_bam* b, const char* bytes, size_t n);                  /* the next bytes of the SAM stream (host; copied) */
 int mkt_bam_add_device(mkt_bam* b, const void* d_bytes, size_t n);         /* alignment lines already on the device */
 int mkt_bam_reserve(mkt_bam* b, size_t bytes);                             /* optional: room for that much alignment text up front */

@@ -17,7 +17,7 @@ EXPORTS = [
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
     "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
     "mkt_rmdup_create", "mkt_rmdup_destroy", "mkt_rmdup_error", "mkt_rmdup_add", "mkt_rmdup_run", "mkt_rmdup_fetch",
-    "mkt_bam_create", "mkt_bam_destroy", "mkt_bam_error", "mkt_bam_add", "mkt_bam_add_device", "mkt_bam_run", "mkt_bam_fetch",
+    "mkt_bam_create", "mkt_bam_destroy", "mkt_bam_error", "mkt_bam_note", "mkt_bam_add", "mkt_bam_add_device", "mkt_bam_run", "mkt_bam_fetch",
     "mkt_bam_reserve", "mkt_bam_window", "mkt_bam_commit", "mkt_bam_read",
 ]
 
@@ -62,6 +62,30 @@ def exe_path():
 _lib = None
 
 
+def hip_runtimes():
+    """The HIP runtime libraries mapped into this process (paths of libamdhip64.so*)."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    found.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return sorted(found)
+
+
+def check_single_hip_runtime():
+    """One HIP runtime per process.  PyTorch bundles its own libamdhip64.so and loads it by file name; libmkt_hip.so asks for the
+    soname.  torch imported FIRST: its copy satisfies the library, one runtime.  The library loaded first: it binds /opt/rocm's
+    copy, torch later maps its own as a SECOND runtime, and one of the two then sees no GPU ("No HIP GPUs are available",
+    hipErrorNoDevice from mkt_create).  Say so instead."""
+    rts = hip_runtimes()
+    if len(rts) > 1:
+        raise MktError("two HIP runtimes are mapped into this process (" + ", ".join(rts) + "): import torch BEFORE microcket_amd "
+                       "(or not at all), so that libmkt_hip.so shares torch's runtime; with two, one of them sees no GPU")
+
+
 def load_library():
     """Loads libmkt_hip.so (raises if it has not been built: there is no fallback)."""
     global _lib
@@ -71,6 +95,7 @@ def load_library():
     if not os.path.exists(path):
         raise MktError(f"{path} is missing: run `python -m microcket_amd.build` (hipcc, gfx950). No CPU path exists.")
     L = C.CDLL(path)
+    check_single_hip_runtime()
     L.mkt_strerror.restype = C.c_char_p
     L.mkt_last_error.restype = C.c_char_p
     L.mkt_last_error.argtypes = [C.c_void_p]
@@ -132,6 +157,8 @@ def load_library():
     L.mkt_bam_destroy.restype = None
     L.mkt_bam_error.argtypes = [C.c_void_p]
     L.mkt_bam_error.restype = C.c_char_p
+    L.mkt_bam_note.argtypes = [C.c_void_p]
+    L.mkt_bam_note.restype = C.c_char_p
     L.mkt_bam_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.mkt_bam_add_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.mkt_bam_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -154,6 +181,7 @@ class Context:
     def __init__(self, mode, ratio=0.5, min_mapq=10, write_sam=True, ref_threads=4, device=0, block_bytes=0, tiles=TILES_AUTO,
                  ordered=False, extensions=0):
         self.L = load_library()
+        check_single_hip_runtime()           # (torch imported after this package: caught here, at the latest)
         if isinstance(mode, str):
             mode = {"flash": MODE_FLASH, "unc": MODE_UNC}[mode]
         self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 1 if ordered else 0, extensions, 0)
@@ -511,8 +539,9 @@ def run_sam2pairs(in_sam, mode, prefix, threads=4, ratio=0.5, mapq=10, sam="yes"
     return p.returncode, p.stdout, p.stderr
 
 
-def sam_to_bam(sam: bytes, sorted=True, level=2, device=0, piece=1 << 24):
-    """SAM text (header lines + alignment lines) -> (BAM bytes, BAI bytes or b"", records) on the GPU: mkt_bam_* in include/mkt.h."""
+def sam_to_bam(sam: bytes, sorted=True, level=2, device=0, piece=1 << 24, notes=None):
+    """SAM text (header lines + alignment lines) -> (BAM bytes, BAI bytes or b"", records) on the GPU: mkt_bam_* in include/mkt.h.
+    notes: a list that receives mkt_bam_note() (why no index was made), if given."""
     L = load_library()
     h = C.c_void_p()
     rc = L.mkt_bam_create(device, C.byref(h))
@@ -535,6 +564,8 @@ def sam_to_bam(sam: bytes, sorted=True, level=2, device=0, piece=1 << 24):
             if rc != 0:
                 raise MktError(f"mkt_bam_fetch: {L.mkt_strerror(rc).decode()}: {L.mkt_bam_error(h).decode()}")
             outs.append(buf.raw[:n])
+        if notes is not None:
+            notes.append(L.mkt_bam_note(h).decode())
         return outs[0], outs[1], nrec.value
     finally:
         L.mkt_bam_destroy(h)

@@ -196,6 +196,7 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
     uint32_t n_cigar = 0;
     int64_t rlen = 0;
     const bool no_cigar = cb - ca == 1 && t[ca] == '*';
+    if (!(flag & 4u) && (pos1 == 0 || tid < 0)) flag |= 4u;  // "mapped query cannot have zero coordinate; treated as unmapped" / no reference (htslib sam_parse1)
     if (no_cigar) { if (!(flag & 4u)) flag |= 4u; }          // "mapped query must have a CIGAR; treated as unmapped"
     else {
         uint64_t v = 0;
@@ -305,7 +306,13 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
                 for (uint32_t i = 0; i < cnt; ++i) {
                     uint64_t e = k;
                     while (e < vb && t[e] != ',') ++e;
-                    if (sub == 'f') (void)dec_f(t, k, e, &tok); else (void)dec_s(t, k, e, &tok);
+                    if (sub == 'f') (void)dec_f(t, k, e, &tok);
+                    else {                                  // every element inside its subtype's range (htslib rejects the line otherwise; no silent wrap)
+                        const int64_t x = dec_s(t, k, e, &tok);
+                        const int64_t lo = sub == 'c' ? -128 : sub == 's' ? -32768 : sub == 'i' ? -2147483648ll : 0;
+                        const int64_t hi = sub == 'c' ? 127 : sub == 'C' ? 255 : sub == 's' ? 32767 : sub == 'S' ? 65535 : sub == 'i' ? 2147483647ll : 4294967295ll;
+                        if (x < lo || x > hi) tok = false;
+                    }
                     k = e + 1;
                 }
             }
@@ -315,7 +322,7 @@ __device__ uint32_t bam_record(const uint8_t* t, uint64_t ls, uint64_t le, const
         p = q + 1;
     }
     if (WRITE) { o.flush(); uint8_t* h = out; put32(h, size - 4); }
-    if (ix) { ix->tid = tid; ix->beg = pos; ix->end = (int32_t)(end > 0x7fffffffll ? 0x7fffffffll : end); ix->bin = bin | ((uint32_t)flag << 16); }
+    if (ix) { ix->tid = tid; ix->beg = pos; ix->end = (int32_t)(end > 0x7fffffffll ? 0x7fffffffll : end); ix->bin = (bin & 0xFFFFu) | ((uint32_t)flag << 16); }      // (a position past 2^29 gives a bin beyond 16 bits: the host makes no index then)
     return size;
 }
 
@@ -919,6 +926,9 @@ __global__ void k_bai(const BamIdx* idx, const uint64_t* off /* [n + 1] */, uint
     int64_t w0 = x.beg < 0 ? 0 : (x.beg >> 14), w1 = (x.end > 0 ? x.end - 1 : 0) >> 14;
     if (w1 < w0) w1 = w0;
     for (int64_t w = w0; w <= w1 && (uint64_t)w < nwin; ++w) atomicMin(&lin[lin_off[x.tid] + (uint64_t)w], (unsigned long long)v0);
+    // a record that reaches past its reference's LN (the linear index is sized by LN) or past the 2^29 bases a BAI can address:
+    // no index can describe it (no_coor[1] != 0 -> the host writes none and says why)
+    if ((uint64_t)w1 >= nwin || x.end > (1 << 29) || bin > 37449u) atomicOr(no_coor + 1, 1ull);
     bool head = r == 0;
     if (!head) { const BamIdx y = idx[r - 1]; head = y.tid != x.tid || (y.bin & 0xFFFFu) != bin; }
     if (head) head_flag[r] = 1;
@@ -954,7 +964,7 @@ struct mkt_bam {
     hipEvent_t ev_io[2] = {nullptr, nullptr};
     bool io_busy[2] = {false, false};
     int io_slot = 0;
-    std::string err;
+    std::string err, note;
 };
 constexpr size_t kBamIoCap = (size_t)64 << 20;
 static int bfail(mkt_bam* s, int code, const char* fmt, ...) {
@@ -1029,6 +1039,7 @@ void mkt_bam_destroy(mkt_bam* s) {
     delete s;
 }
 const char* mkt_bam_error(const mkt_bam* s) { return s ? s->err.c_str() : ""; }
+const char* mkt_bam_note(const mkt_bam* s) { return s ? s->note.c_str() : ""; }
 
 // The next bytes of the SAM stream (any chunking).  Leading '@' lines are the header; everything from the first other line on
 // is alignment text and goes to the device.
@@ -1344,6 +1355,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
 
     // ---- BAI (coordinate order only; the format ends at 2^29 bases per reference -- longer ones would need a CSI index: none is made then)
     s->bai.clear();
+    s->note.clear();
     bool bai_ok = true;
     for (uint32_t i = 0; i < nref; ++i) if (lens[i] > (1u << 29)) bai_ok = false;
     if (sorted && bai_ok) {
@@ -1358,7 +1370,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
         std::vector<BaiRef> refs(nref);
         std::vector<unsigned long long> lin(nlin);
         std::vector<BaiHead> heads;
-        unsigned long long no_coor = 0;
+        unsigned long long no_coor = 0, beyond = 0;
         std::vector<BaiRef> init(nref);
         for (auto& r : init) { r.n_mapped = 0; r.n_unmapped = 0; r.beg = ~0ull; r.end = 0; }
         BALLOC(d_lin_off, (nref + 1) * sizeof(uint64_t));
@@ -1379,6 +1391,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
             BRUN(hipMemcpyAsync(&nheads, d_hflag + nl, sizeof nheads, hipMemcpyDeviceToHost, st));
         }
         BRUN(hipMemcpyAsync(&no_coor, d_nocoor, sizeof no_coor, hipMemcpyDeviceToHost, st));
+        BRUN(hipMemcpyAsync(&beyond, d_nocoor + 1, sizeof beyond, hipMemcpyDeviceToHost, st));
         if (nref) BRUN(hipMemcpyAsync(refs.data(), d_refs, nref * sizeof(BaiRef), hipMemcpyDeviceToHost, st));
         if (nlin) BRUN(hipMemcpyAsync(lin.data(), d_lin, nlin * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BRUN(hipStreamSynchronize(st));
@@ -1404,7 +1417,7 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
             off_end = (cb << 16) | (uo - b * BGZF_RAW);
         }
         // per reference (the run starts come in file order = by reference): a stable counting sort by bin
-        std::vector<uint32_t> bin_cnt(37452, 0), bin_at(37452, 0);
+        std::vector<uint32_t> bin_cnt(65536, 0), bin_at(65536, 0);      // (every 16-bit value: a record past 2^29 bases carries a bin beyond 37449; no index is kept then, see below)
         std::vector<uint32_t> order(nheads);
         std::vector<std::pair<size_t, size_t>> ref_range(nref, {0, 0});
         {
@@ -1456,7 +1469,13 @@ int mkt_bam_run(mkt_bam* s, int sorted, int level, uint64_t* records, uint64_t* 
             for (uint64_t k = a; k < last; ++k) put_le64(o, lin[k]);
         }
         put_le64(o, no_coor);
+        if (beyond) {
+            s->bai.clear();
+            s->note = "no index written: a record lies past its reference's LN or past the 2^29 bases a BAI index can address (samtools index would need -c)";
+        }
         mark("BAI");
+    } else if (sorted) {
+        s->note = "no index written: a reference is longer than the 2^29 bases a BAI index can address (samtools index would need -c)";
     }
     cleanup();
 #undef BALLOC

@@ -250,16 +250,22 @@ __global__ void k_tie_small(SortRec* rec, uint64_t n, const uint8_t* text, const
     }
     for (uint32_t k = 0; k < (uint32_t)L; ++k) rec[j + k].idx = ix[k];
 }
-// long runs (heavily duplicated contacts): one workgroup per run ranks every line against all others
-constexpr uint32_t kMaxRun = 1u << 16;
-__global__ __launch_bounds__(SWG) void k_tie_big(SortRec* rec, uint64_t n, const uint8_t* text, const uint64_t* starts, const uint32_t* big_list, uint32_t* tmp, uint32_t* err) {
+// long runs (heavily duplicated contacts): one workgroup per run ranks every line against all others; a run of more than kMaxRun
+// lines (a pile-up locus in deep data) is put on the huge list instead: the host gives it the whole GPU (k_tie_huge)
+constexpr uint32_t kMaxRun = 1u << 11;
+constexpr uint32_t kHugeCap = 4096;
+__global__ __launch_bounds__(SWG) void k_tie_big(SortRec* rec, uint64_t n, const uint8_t* text, const uint64_t* starts, const uint32_t* big_list, uint32_t* tmp, uint32_t* err,
+                                                 uint64_t* huge /* [2 kHugeCap]: head, length */, uint32_t* huge_count) {
     __shared__ uint32_t sL;
     const uint64_t j = big_list[blockIdx.x];
     if (threadIdx.x == 0) {
         uint64_t L = 1;
         while (j + L < n && key_same(rec[j + L], rec[j])) ++L;
         sL = L > kMaxRun ? 0u : (uint32_t)L;
-        if (L > kMaxRun) atomicOr(err, (uint32_t)SE_RUN);
+        if (L > kMaxRun) {
+            const uint32_t k = atomicAdd(huge_count, 1u);
+            if (k < kHugeCap) { huge[2 * k] = j; huge[2 * k + 1] = L; } else atomicOr(err, (uint32_t)SE_RUN);
+        }
     }
     __syncthreads();
     const uint32_t L = sL;
@@ -276,6 +282,25 @@ __global__ __launch_bounds__(SWG) void k_tie_big(SortRec* rec, uint64_t n, const
     __syncthreads();
     __threadfence_block();
     for (uint32_t i = threadIdx.x; i < L; i += SWG) rec[j + i].idx = tmp[j + i];
+}
+
+// one huge run [j, j + L): every line ranked against all others, one lane per line, as many workgroups as the run needs (O(L^2)
+// whole-line comparisons spread over the chip: slow, but GNU sort has no limit here either); then the ranks become the order
+__global__ __launch_bounds__(SWG) void k_tie_huge(const SortRec* rec, const uint8_t* text, const uint64_t* starts, uint64_t j, uint64_t L, uint32_t* tmp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const uint32_t me = rec[j + i].idx;
+    uint64_t r = 0;
+    for (uint64_t k = 0; k < L; ++k) {
+        if (k == i) continue;
+        const uint32_t o = rec[j + k].idx;
+        if (line_less(text, starts, o, me) || (k < i && !line_less(text, starts, me, o))) ++r;
+    }
+    tmp[j + r] = me;
+}
+__global__ void k_tie_huge_apply(SortRec* rec, uint64_t j, uint64_t L, const uint32_t* tmp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) rec[j + i].idx = tmp[j + i];
 }
 
 // ---- gather the lines in sorted order ---------------------------------------------------------------------------
@@ -472,12 +497,13 @@ int mkt_sorter_sort(mkt_sorter* s, uint64_t* lines, uint64_t* bytes) {
     ChrTab* d_tab = nullptr;
     uint32_t *d_hist = nullptr, *d_err = nullptr, *d_big = nullptr, *d_tmp = nullptr;
     uint16_t* d_rank = nullptr;
-    const uint32_t big_cap = 1u << 20;
+    uint64_t* d_huge = nullptr;
     SALLOC(d_starts, (nl + 2) * sizeof(uint64_t));
     SALLOC(rA, (nl + 1) * sizeof(SortRec));
     SALLOC(rB, (nl + 1) * sizeof(SortRec));
     SALLOC(d_tab, sizeof(ChrTab));
     SALLOC(d_hist, (size_t)16 * 1024 * 4 + 256);
+    const uint32_t big_cap = (uint32_t)(nl / (kSmallRun + 1) + 1);          // (every long run has more than kSmallRun lines: always enough)
     SALLOC(d_err, 256);
     SALLOC(d_big, (size_t)big_cap * 4);
     SALLOC(d_rank, kChrSlots * sizeof(uint16_t));
@@ -489,7 +515,7 @@ int mkt_sorter_sort(mkt_sorter* s, uint64_t* lines, uint64_t* bytes) {
     // dictionary ranks of the chromosome names (host: at most 8192 short strings)
     std::vector<unsigned long long> hh(kChrSlots);
     std::vector<uint8_t> names((size_t)kChrSlots * 64);
-    uint32_t herr[2] = {0, 0};
+    uint32_t herr[3] = {0, 0, 0};      // error bits, long runs, huge runs
     SRUN(hipMemcpyAsync(hh.data(), d_tab->hash, kChrSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     SRUN(hipMemcpyAsync(names.data(), d_tab->name, names.size(), hipMemcpyDeviceToHost, st));
     SRUN(hipMemcpyAsync(herr, d_err, sizeof herr, hipMemcpyDeviceToHost, st));
@@ -532,11 +558,24 @@ int mkt_sorter_sort(mkt_sorter* s, uint64_t* lines, uint64_t* bytes) {
     if (herr[1]) {
         if (herr[1] > big_cap) { cleanup(); return sfail(s, MKT_E_CAPACITY, "more than %u long runs of equal sort keys", big_cap); }
         SALLOC(d_tmp, (nl + 1) * sizeof(uint32_t));
-        hipLaunchKernelGGL(k_tie_big, dim3(herr[1]), dim3(SWG), 0, st, rA, nl, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, (const uint32_t*)d_big, d_tmp, d_err);
+        SALLOC(d_huge, (size_t)2 * kHugeCap * sizeof(uint64_t));
+        hipLaunchKernelGGL(k_tie_big, dim3(herr[1]), dim3(SWG), 0, st, rA, nl, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, (const uint32_t*)d_big, d_tmp, d_err, d_huge, d_err + 2);
         SRUN(hipMemcpyAsync(herr, d_err, sizeof herr, hipMemcpyDeviceToHost, st));
         SRUN(hipStreamSynchronize(st));
+        if (herr[2] && !(herr[0] & SE_RUN)) {                          // runs of more than kMaxRun equal keys: the whole chip per run
+            std::vector<uint64_t> huge((size_t)2 * herr[2]);
+            SRUN(hipMemcpy(huge.data(), d_huge, huge.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            for (uint32_t k = 0; k < herr[2]; ++k) {
+                const uint64_t j = huge[2 * k], L = huge[2 * k + 1];
+                const unsigned g = (unsigned)((L + SWG - 1) / SWG);
+                hipLaunchKernelGGL(k_tie_huge, dim3(g), dim3(SWG), 0, st, (const SortRec*)rA, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, j, L, d_tmp);
+                hipLaunchKernelGGL(k_tie_huge_apply, dim3(g), dim3(SWG), 0, st, rA, j, L, (const uint32_t*)d_tmp);
+            }
+            SRUN(hipGetLastError());
+            SRUN(hipStreamSynchronize(st));
+        }
     }
-    if (herr[0] & SE_RUN) { cleanup(); return sfail(s, MKT_E_CAPACITY, "a run of more than %u lines with the same (chr1, chr2, pos1, pos2)", kMaxRun); }
+    if (herr[0] & SE_RUN) { cleanup(); return sfail(s, MKT_E_CAPACITY, "more than %u runs of more than %u lines with the same (chr1, chr2, pos1, pos2)", kHugeCap, kMaxRun); }
     // gather
     const uint32_t wg = (uint32_t)((nl + LPW - 1) / LPW);
     uint64_t* d_wsum = nullptr;

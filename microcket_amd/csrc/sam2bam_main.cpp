@@ -127,10 +127,19 @@ int main(int argc, char** argv) {
     rc = mkt_bam_run(b, sorted, level, &nrec, &nbam, &nbai);
     if (rc != MKT_OK) return fail(rc == MKT_E_ARG ? 23 : 21, "mkt_bam_run");
     mark("mkt_bam_run");
+    if (sorted && index && out != "-" && !nbai && mkt_bam_note(b)[0]) fprintf(stderr, "sam2bam: WARN: %s\n", mkt_bam_note(b));
     const int ofd = out == "-" ? 1 : open(out.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
     if (ofd < 0) { fprintf(stderr, "sam2bam: cannot open %s: %s\n", out.c_str(), strerror(errno)); mkt_bam_destroy(b); return 11; }
     struct stat osb;
-    const bool oregular = fstat(ofd, &osb) == 0 && S_ISREG(osb.st_mode);
+    // positioned parallel writes only into a regular file we may seek in: stdout redirected with >> (O_APPEND) or handed over at
+    // an offset takes the bytes in order, from where it stands
+    bool oregular = fstat(ofd, &osb) == 0 && S_ISREG(osb.st_mode);
+    off_t obase = 0;
+    if (oregular && ofd == 1) {
+        const int fl = fcntl(ofd, F_GETFL);
+        obase = lseek(ofd, 0, SEEK_CUR);
+        if (fl < 0 || (fl & O_APPEND) || obase < 0) { oregular = false; obase = 0; }
+    }
     const size_t piece = (size_t)64 << 20;
     for (uint64_t off = 0; off < nbam; off += piece) {
         const size_t n = (size_t)(nbam - off < piece ? nbam - off : piece);
@@ -149,7 +158,7 @@ int main(int argc, char** argv) {
                 th.emplace_back([&, t, lo, hi]() {
                     size_t done = lo;
                     while (done < hi) {
-                        const ssize_t k = pwrite(ofd, src + done, hi - done, (off_t)(off + done));
+                        const ssize_t k = pwrite(ofd, src + done, hi - done, obase + (off_t)(off + done));
                         if (k < 0) { if (errno == EINTR) continue; badv[(size_t)t] = 1; break; }
                         done += (size_t)k;
                     }
@@ -158,7 +167,7 @@ int main(int argc, char** argv) {
             for (auto& x : th) x.join();
             for (int v : badv) bad = bad || v;
         } else {
-            if (oregular && lseek(ofd, (off_t)off, SEEK_SET) < 0) bad = true;
+            if (oregular && lseek(ofd, obase + (off_t)off, SEEK_SET) < 0) bad = true;
             size_t done = 0;
             while (!bad && done < n) {
                 const ssize_t k = write(ofd, src + done, n - done);
@@ -168,6 +177,7 @@ int main(int argc, char** argv) {
         }
         if (bad) { fprintf(stderr, "sam2bam: write error on %s\n", out.c_str()); mkt_bam_destroy(b); return 22; }
     }
+    if (ofd == 1 && oregular && lseek(ofd, obase + (off_t)nbam, SEEK_SET) < 0) { fprintf(stderr, "sam2bam: write error on %s\n", out.c_str()); mkt_bam_destroy(b); return 22; }
     if (ofd != 1 && close(ofd) != 0) { fprintf(stderr, "sam2bam: write error on %s\n", out.c_str()); mkt_bam_destroy(b); return 22; }
     if (sorted && index && out != "-" && nbai) {
         const std::string ip = out + ".bai";

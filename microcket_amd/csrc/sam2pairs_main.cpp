@@ -32,6 +32,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include "../../include/mkt.h"
@@ -117,10 +118,31 @@ int main(int argc, char* argv[]) {
     // Outputs: a writer thread takes the published chunks straight out of the library's pinned staging buffers
     // (mkt_drain_wait) while this thread keeps reading; a slow consumer of stdout throttles the pipeline by itself.
     // After a write error the chunks are still taken (and dropped) so that nothing upstream blocks.
-    int io_threads = (e = getenv("MKT_IO_THREADS")) ? atoi(e) : 16;       // readers of a regular input file (measured: 16 > 8 > 32)
+    // Threads that copy: readers of a regular input file (pread into the pinned block) and writers of big .sam chunks (pwrite).
+    // They share the CPUs this process may use -- its cgroup quota, not what hardware_concurrency() reports: a container with 16 of
+    // 256 CPUs that runs 16 readers AND 8 writers is throttled by the scheduler for the rest of every period (measured, r03
+    // samyes_probe: sam=yes 1.83 s with 16 + 8 threads, 1.08 s with 8 + 4; the .sam to /dev/null: 0.38 s).  sam=no: 16 readers
+    // (measured: 16 > 8 > 32); sam=yes: half the CPUs read, a quarter writes.
+    unsigned cpus = std::thread::hardware_concurrency();
+    if (!cpus) cpus = 16;
+    {
+        FILE* fq = fopen("/sys/fs/cgroup/cpu.max", "r");
+        long long quota = 0, period = 0;
+        char q[32] = {0};
+        if (fq) {
+            if (fscanf(fq, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota = atoll(q);
+            fclose(fq);
+        }
+        if (quota > 0) { const unsigned qc = (unsigned)((quota + period - 1) / period); if (qc && qc < cpus) cpus = qc; }
+    }
+    int io_threads = (e = getenv("MKT_IO_THREADS")) ? atoi(e) : (p.write_sam ? (int)(cpus / 2) : 16);
     if (io_threads < 1) io_threads = 1;
-    { const unsigned hc = std::thread::hardware_concurrency(); if (hc && (unsigned)io_threads > hc) io_threads = (int)hc; }
-    const int w_threads = io_threads < 8 ? io_threads : 8;                   // writers of a big .sam chunk: more than 8 get in each other's way
+    if ((unsigned)io_threads > cpus) io_threads = (int)cpus;
+    if (io_threads > 32) io_threads = 32;
+    int w_threads = (int)(cpus / 4);
+    if (w_threads > 8) w_threads = 8;                                        // (more than 8 get in each other's way)
+    if (w_threads < 1) w_threads = 1;
+    if ((e = getenv("MKT_W_THREADS")) && atoi(e) > 0) w_threads = atoi(e);
     auto write_all = [](int fd, const char* p, size_t n) -> bool {
         while (n) {
             const ssize_t k = write(fd, p, n);
@@ -147,6 +169,9 @@ int main(int argc, char* argv[]) {
                     else if (!write_all(1, o.pairs, o.pairs_len)) write_failed = 1;
                 }
                 if (fsam && o.sam_len) {
+                    // (A write() into one file holds the inode's lock while it copies, so the pwrite slices below take turns on tmpfs:
+                    //  ~8 GB/s whatever their number.  Copying into a mapping of the grown file instead -- page faults take no
+                    //  inode lock -- measured SLOWER, 1.69 s against 1.15 s for a 7.6 GB input: gpurun_out/r03p, tools/samyes_probe.py.)
                     if (sam_regular && o.sam_len >= ((size_t)8 << 20) && w_threads > 1) {
                         // the page-cache copy of one thread is a few GB/s: big chunks go out as disjoint pwrite slices
                         const size_t slice = ((o.sam_len + (size_t)w_threads - 1) / (size_t)w_threads + 4095) & ~(size_t)4095;
@@ -191,6 +216,9 @@ int main(int argc, char* argv[]) {
     const int fd = fileno(fin);
     struct stat sb;
     const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+#if defined(F_SETPIPE_SZ)
+    if (!regular && S_ISFIFO(sb.st_mode)) (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);      // a bigger pipe: fewer wake-ups per GB between the aligner and us (best effort)
+#endif
     off_t fpos = regular ? lseek(fd, 0, SEEK_CUR) : 0;
     if (regular && fpos < 0) fpos = 0;
     for (;;) {

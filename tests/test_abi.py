@@ -77,3 +77,15 @@ def test_executable_exit_codes_without_gpu(tmp_path):
     if m.device_count() == 0:
         r = subprocess.run([exe, str(sam), "unc", str(tmp_path / "o"), "4"], stderr=subprocess.PIPE, stdout=subprocess.PIPE)
         assert r.returncode == 20 and r.stdout == b""                                   # no GPU: loud failure, no output
+
+
+def test_two_hip_runtimes_are_reported(monkeypatch):
+    """capi.check_single_hip_runtime: a process that holds two libamdhip64.so (this package loaded before torch) gets a one-line
+    explanation instead of "No HIP GPUs are available" -- checked on the parser and the message, no GPU needed."""
+    from microcket_amd import capi
+    assert isinstance(capi.hip_runtimes(), list)
+    monkeypatch.setattr(capi, "hip_runtimes", lambda: ["/opt/rocm/lib/libamdhip64.so.7", "/usr/lib/python3/torch/lib/libamdhip64.so"])
+    with pytest.raises(capi.MktError, match="import torch BEFORE"):
+        capi.check_single_hip_runtime()
+    monkeypatch.setattr(capi, "hip_runtimes", lambda: ["/opt/rocm/lib/libamdhip64.so.7"])
+    capi.check_single_hip_runtime()

@@ -204,6 +204,29 @@ def test_errors_are_reported():
     big = b"@SQ\tSN:chrBig\tLN:600000000\n"                          # beyond the BAI format: a BAM, but no index
     bam_b, bai_b, n = m.sam_to_bam(big + b"r\t0\tchrBig\t550000000\t0\t1M\t*\t0\t0\tA\tI\n")
     assert n == 1 and bai_b == b"" and bamio.Bam(bam_b).records[0][2]["pos"] == 549999999
+    # a POSITION beyond the BAI format, or beyond what the linear index of its (short) reference holds: still a BAM, no index, the
+    # reason noted
+    for pos in (600000000, (1 << 29) + 1, 40000):
+        notes = []
+        bam_b, bai_b, n = m.sam_to_bam(hdr + ok + b"q\t0\tchr1\t%d\t0\t1M\t*\t0\t0\tA\tI\n" % pos, notes=notes)
+        assert n == 2 and bai_b == b"" and "no index" in notes[0], (pos, notes)
+        assert sorted(r[2]["pos"] for r in bamio.Bam(bam_b).records) == [0, pos - 1]
+    for pos in (1000, 5000):                                          # the last base of the reference / past LN but inside its last index window
+        notes = []
+        bam_b, bai_b, n = m.sam_to_bam(hdr + ok + b"q\t0\tchr1\t%d\t0\t1M\t*\t0\t0\tA\tI\n" % pos, notes=notes)
+        assert n == 2 and bai_b != b"" and notes == [""]
+    # integer B arrays: every element inside its subtype's range
+    for tag, good in ((b"XB:B:c,-128,127", True), (b"XB:B:c,300", False), (b"XB:B:C,255", True), (b"XB:B:C,-1", False), (b"XB:B:s,-32768,32767", True),
+                      (b"XB:B:S,65536", False), (b"XB:B:i,-2147483648", True), (b"XB:B:I,4294967295", True), (b"XB:B:I,4294967296", False)):
+        line = b"r\t0\tchr1\t1\t0\t1M\t*\t0\t0\tA\tI\t" + tag + b"\n"
+        if good:
+            assert m.sam_to_bam(hdr + line)[2] == 1
+        else:
+            with pytest.raises(m.MktError):
+                m.sam_to_bam(hdr + line)
+    # "mapped query cannot have zero coordinate; treated as unmapped" (htslib): POS 0 or RNAME * without FLAG 4
+    bam_b, bai_b, n = m.sam_to_bam(hdr + b"z\t0\tchr1\t0\t0\t1M\t*\t0\t0\tA\tI\n" + b"y\t16\t*\t0\t0\t*\t*\t0\t0\tA\tI\n")
+    assert sorted(r[2]["flag"] for r in bamio.Bam(bam_b).records) == [4, 20]
     bam_b, bai_b, n = m.sam_to_bam(hdr)                               # header only
     assert n == 0 and bamio.Bam(bam_b).refs == [("chr1", 1000)]
     bam_b, bai_b, n = m.sam_to_bam(b"")
@@ -228,6 +251,21 @@ def test_executable_replaces_view_sort_index(tmp_path):
     # the same through a pipe, unsorted
     r = subprocess.run([exe, "-u", "-o", "-", "-"], input=hdr + a + c, capture_output=True)
     assert r.returncode == 0, r.stderr
+    # stdout appended to a regular file (>>) and handed over at an offset: the BAM follows what is there
+    for mode in ("ab", "r+b"):
+        tgt = tmp_path / ("app_" + mode[0] + ".bin")
+        tgt.write_bytes(b"PREFIX--")
+        with open(tgt, mode) as fo:
+            if mode == "r+b":
+                fo.seek(8)
+            rr = subprocess.run([exe, "-o", "-", str(tmp_path / "h.sam"), str(tmp_path / "a.sam"), str(tmp_path / "c.sam")], stdout=fo, stderr=subprocess.PIPE)
+        assert rr.returncode == 0, rr.stderr
+        got = tgt.read_bytes()
+        assert got[:8] == b"PREFIX--" and got[8:] == out.read_bytes(), mode
+    # an index that cannot be written is announced
+    (tmp_path / "far.sam").write_bytes(b"far\t0\t" + hdr.split(b"SN:")[1].split(b"\t")[0] + b"\t600000000\t60\t1M\t*\t0\t0\tA\tI\n")
+    rr = subprocess.run([exe, "-o", str(tmp_path / "far.bam"), str(tmp_path / "h.sam"), str(tmp_path / "far.sam")], capture_output=True)
+    assert rr.returncode == 0 and b"WARN" in rr.stderr and b"no index" in rr.stderr and not (tmp_path / "far.bam.bai").exists(), rr.stderr
     check_bam(hdr, a + c, r.stdout, b"", len((a + c).splitlines()), False, order)
     r = subprocess.run([exe, "-o", str(out), str(tmp_path / "nothing.sam")], capture_output=True)
     assert r.returncode != 0

@@ -255,6 +255,18 @@ def test_two_contexts_as_two_shards():
     assert shard.format_log(dict(zip(shard.COUNTERS, sums))) == lo
 
 
+def test_executable_clean_exit_switch(tmp_path):
+    """MKT_CLEAN_EXIT=1: the executable tears its context down (mkt_destroy) instead of leaving through _exit(0); same bytes, same
+    files, exit code 0 -- what a leak checker runs, and the only path on which a destructor-time error could ever surface."""
+    _need_gpu()
+    text = util.synth("stress", 77, 9000)
+    po, so, lo, st = util.oracle_run(text, "unc", 4, 0.5, 10, True)
+    for env in ({"MKT_CLEAN_EXIT": "1"}, {"MKT_CLEAN_EXIT": "1", "MKT_BLOCK_MB": "1"}, {}):
+        rc, out, sam, log, err = util.cli_run(m.exe_path(), text, "unc", 4, 0.5, 10, True, env=env)
+        assert rc == 0, err
+        assert util.canon(out) == util.canon(po) and util.canon(sam) == util.canon(so) and log == lo, env
+
+
 def _line_multiset_checksum(buf: bytes) -> int:
     """Order-independent 64-bit checksum of the lines of buf (vectorised polynomial hash per line, summed)."""
     a = np.frombuffer(buf, dtype=np.uint8)

@@ -49,6 +49,25 @@ def test_sorted_pairs_equal_gnu_sort(tmp_path):
         assert s.sort() == b""
 
 
+def test_huge_runs_of_equal_keys_are_slow_but_never_an_error(tmp_path):
+    """A pile-up locus: 70,000 lines with the same (chr1, chr2, pos1, pos2) -- more than one workgroup ranks -- plus a second run of
+    5,000 and ordinary lines around them.  GNU sort has no limit here (its last-resort comparison is the whole line); neither has
+    the sorter: runs beyond 2,048 lines are ranked by the whole GPU (k_tie_huge)."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    big = b"".join(b"A00123:45:HXXXXXXXX:%d:%d:%d:%d\tchr3\t777777\tchr3\t888888\t%s\t%s\n" % (1 + k % 4, 1101 + (k * 7919) % 1500, (k * 104729) % 30000, (k * 1299709) % 20000,
+                                                                                             b"+-"[k % 2:k % 2 + 1], b"-+"[(k // 2) % 2:(k // 2) % 2 + 1]) for k in range(70000))
+    mid = b"".join(b"m%06d\tchr3\t777777\tchr3\t888889\t+\t-\n" % ((k * 31337) % 5000) for k in range(5000))
+    rest = _pairs("unc", 905, 20000, "unc")
+    rl, bl = rest.splitlines(keepends=True), big.splitlines(keepends=True)
+    data = b"".join(rl[:len(rl) // 2] + bl[:len(bl) // 2]) + mid + b"".join(rl[len(rl) // 2:] + bl[len(bl) // 2:])
+    with m.PairsSorter(0) as s:
+        for k in range(0, len(data), 1 << 20):
+            s.add(data[k:k + (1 << 20)])
+        got = s.sort()
+    assert got == _gnu_sort(data, tmp_path)
+
+
 def test_sorter_rejects_what_is_not_pairs_text():
     if m.device_count() < 1:
         pytest.fail("no HIP device")
