@@ -1,6 +1,7 @@
 """ctypes binding of include/mkt.h (libmkt_hip.so).  Plumbing only: no record is ever touched here."""
 import ctypes as C
 import os
+import sys
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -95,7 +96,8 @@ def load_library():
     if not os.path.exists(path):
         raise MktError(f"{path} is missing: run `python -m microcket_amd.build` (hipcc, gfx950). No CPU path exists.")
     L = C.CDLL(path)
-    check_single_hip_runtime()
+    if "torch" in sys.modules:
+        check_single_hip_runtime()           # torch came first and the library still brought a second runtime: say so now
     L.mkt_strerror.restype = C.c_char_p
     L.mkt_last_error.restype = C.c_char_p
     L.mkt_last_error.argtypes = [C.c_void_p]
@@ -181,14 +183,16 @@ class Context:
     def __init__(self, mode, ratio=0.5, min_mapq=10, write_sam=True, ref_threads=4, device=0, block_bytes=0, tiles=TILES_AUTO,
                  ordered=False, extensions=0):
         self.L = load_library()
-        check_single_hip_runtime()           # (torch imported after this package: caught here, at the latest)
         if isinstance(mode, str):
             mode = {"flash": MODE_FLASH, "unc": MODE_UNC}[mode]
         self.params = Params(mode, ratio, min_mapq, 1 if write_sam else 0, ref_threads, device, block_bytes, tiles, 1 if ordered else 0, extensions, 0)
         self.h = C.c_void_p()
         rc = self.L.mkt_create(C.byref(self.params), C.byref(self.h))
         if rc != 0:
-            raise MktError(f"mkt_create: {self.L.mkt_strerror(rc).decode()}: {self.L.mkt_last_error(None).decode()}")
+            hint = ""
+            if len(hip_runtimes()) > 1:      # (this package loaded before torch: the usual reason for "no device" on a GPU box)
+                hint = " [two HIP runtimes are mapped into this process (" + ", ".join(hip_runtimes()) + "): import torch BEFORE microcket_amd]"
+            raise MktError(f"mkt_create: {self.L.mkt_strerror(rc).decode()}: {self.L.mkt_last_error(None).decode()}{hint}")
 
     def _chk(self, rc, what):
         if rc != 0:
