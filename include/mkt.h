@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 7
+#define MKT_ABI_VERSION 8
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -207,6 +207,11 @@ int mkt_ext_keys_device(mkt_ctx* ctx, int drop_last, const void** d_keys, uint64
 int mkt_ext_partition(mkt_ctx* ctx, int drop_last, const uint16_t* lut, uint32_t world, void* d_send, uint64_t* counts);
 int mkt_ext_dedup_device(mkt_ctx* ctx, const void* d_keys, uint64_t n, uint8_t* d_flags, uint64_t* dups);
 int mkt_ext_unpartition(mkt_ctx* ctx, const uint8_t* d_flags_part, uint8_t* flags, size_t flags_cap, uint64_t* dups);
+/* The whole exchange for `world` contexts of ONE process (one per GPU; shard r = ctxs[r], contiguous ranges of the input in rank
+ * order; last_rank holds the input's end: its last group is dropped, quirk Q1): partition, device-to-device copies between the
+ * contexts' GPUs (hipMemcpyPeerAsync: xGMI between two GPUs of a node), marking, flags back.  totals[r] / dups[r]: reported pairs /
+ * duplicates of shard r; flags[r] (may be NULL): its flags in input order.  This is what bin/sam2pairs uses with MKT_DEVICES. */
+int mkt_ext_dedup_multi(mkt_ctx** ctxs, uint32_t world, uint32_t last_rank, uint64_t* totals, uint64_t* dups, uint8_t** flags, const size_t* flags_cap);
 
 /* Per-chromosome contact counts of the reported pairs: lines "chrA\tchrB\tcount\n" sorted bytewise by (chrA, chrB). */
 int mkt_ext_chrstat(mkt_ctx* ctx, int drop_last, char* out, size_t cap, size_t* len);

@@ -1214,6 +1214,129 @@ int mkt_ext_unpartition(mkt_ctx* c, const uint8_t* d_flags_part, uint8_t* flags,
     if (dups) *dups = c->h_dd_res->dups;
     return MKT_OK;
 }
+// Duplicate marking across the contexts of ONE process (one context per GPU, contiguous shards of the input in rank order): the
+// in-process form of microcket_amd/shard.py's exchange.  Every key record travels to the context mix64(key) % world -- device to
+// device, hipMemcpyPeerAsync: between two GPUs of one node that is one xGMI hop, nothing passes through the host --, is marked
+// there together with the equal keys of all other shards (segments are laid down in source-rank order and the partition is
+// stable, so "first in input order wins" holds globally), and one byte per record travels back the same way.
+int mkt_ext_dedup_multi(mkt_ctx** cs, uint32_t world, uint32_t last_rank, uint64_t* totals, uint64_t* dups, uint8_t** flags, const size_t* flags_cap) {
+    if (!cs || world == 0 || world > 16 || !totals || !dups) return MKT_E_ARG;
+    for (uint32_t r = 0; r < world; ++r) {
+        if (!cs[r]) return MKT_E_ARG;
+        if (!(cs[r]->p.extensions & MKT_EXT_KEYS)) return fail(cs[r], MKT_E_STATE, "context created without MKT_EXT_KEYS");
+        if ((cs[r]->p.extensions ^ cs[0]->p.extensions) & MKT_EXT_LANES) return fail(cs[r], MKT_E_ARG, "contexts disagree on MKT_EXT_LANES");
+    }
+    mkt_ctx* c0 = cs[0];
+    // chromosome slots are per context: every slot -> the rank of its name in the sorted union of all tables
+    std::vector<std::vector<std::pair<uint32_t, std::string>>> tabs(world);
+    std::vector<std::string> uni;
+    for (uint32_t r = 0; r < world; ++r) {
+        size_t len = 0;
+        int rc = mkt_ext_chr_names(cs[r], nullptr, 0, &len);
+        if (rc) return rc;
+        std::string txt(len, '\0');
+        if (len && (rc = mkt_ext_chr_names(cs[r], &txt[0], len, &len))) return rc;
+        size_t p0 = 0;
+        while (p0 < txt.size()) {
+            const size_t nl = txt.find('\n', p0), tb = txt.find('\t', p0);
+            if (nl == std::string::npos || tb == std::string::npos || tb > nl) break;
+            tabs[r].push_back({(uint32_t)atoi(txt.substr(p0, tb - p0).c_str()), txt.substr(tb + 1, nl - tb - 1)});
+            uni.push_back(tabs[r].back().second);
+            p0 = nl + 1;
+        }
+    }
+    std::sort(uni.begin(), uni.end());
+    uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+    if (uni.size() > kChrSlots) return fail(c0, MKT_E_CAPACITY, "more than %u chromosome names over all shards", kChrSlots);
+    struct Side { uint8_t* d_send = nullptr; uint8_t* d_recv = nullptr; uint8_t* d_flags = nullptr; uint8_t* d_back = nullptr; uint64_t n = 0, nrecv = 0; uint64_t cnt[16]; };
+    std::vector<Side> sd(world);
+    auto cleanup = [&]() {
+        for (uint32_t r = 0; r < world; ++r) {
+            (void)hipSetDevice(cs[r]->p.device);
+            if (sd[r].d_send) (void)hipFree(sd[r].d_send);
+            if (sd[r].d_recv) (void)hipFree(sd[r].d_recv);
+            if (sd[r].d_flags) (void)hipFree(sd[r].d_flags);
+            if (sd[r].d_back) (void)hipFree(sd[r].d_back);
+        }
+    };
+#define MCHK(c, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail((c), MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    // partition every shard's keys by destination (stable), slots rewritten to the shared ids
+    for (uint32_t r = 0; r < world; ++r) {
+        mkt_ctx* c = cs[r];
+        std::vector<uint16_t> lut(kChrSlots, 0);
+        for (const auto& e : tabs[r]) lut[e.first & (kChrSlots - 1)] = (uint16_t)(std::lower_bound(uni.begin(), uni.end(), e.second) - uni.begin());
+        int rc = mkt_sync(c);
+        if (rc) { cleanup(); return rc; }
+        sd[r].n = ext_key_count(c, r == last_rank);
+        totals[r] = sd[r].n;
+        for (uint32_t d = 0; d < 16; ++d) sd[r].cnt[d] = 0;
+        if (sd[r].n) MCHK(c, hipMalloc((void**)&sd[r].d_send, (size_t)sd[r].n * sizeof(KeyRec)));
+        rc = mkt_ext_partition(c, r == last_rank, lut.data(), world, sd[r].d_send, sd[r].cnt);
+        if (rc) { cleanup(); return rc; }
+    }
+    for (uint32_t a = 0; a < world; ++a)                         // direct device-to-device copies where the hardware offers them (best effort)
+        for (uint32_t b = 0; b < world; ++b)
+            if (cs[a]->p.device != cs[b]->p.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, cs[a]->p.device, cs[b]->p.device) == hipSuccess && can) {
+                    (void)hipSetDevice(cs[a]->p.device);
+                    const hipError_t e = hipDeviceEnablePeerAccess(cs[b]->p.device, 0);
+                    if (e != hipSuccess) (void)hipGetLastError();      // (already enabled: fine)
+                }
+            }
+    // the exchange: rank r receives, in source-rank order, what every rank s partitioned for it
+    for (uint32_t r = 0; r < world; ++r) {
+        mkt_ctx* c = cs[r];
+        MCHK(c, hipSetDevice(c->p.device));
+        sd[r].nrecv = 0;
+        for (uint32_t s2 = 0; s2 < world; ++s2) sd[r].nrecv += sd[s2].cnt[r];
+        if (!sd[r].nrecv) continue;
+        MCHK(c, hipMalloc((void**)&sd[r].d_recv, (size_t)sd[r].nrecv * sizeof(KeyRec)));
+        MCHK(c, hipMalloc((void**)&sd[r].d_flags, (size_t)sd[r].nrecv));
+        uint64_t at = 0;
+        for (uint32_t s2 = 0; s2 < world; ++s2) {
+            uint64_t soff = 0;
+            for (uint32_t d = 0; d < r; ++d) soff += sd[s2].cnt[d];
+            const uint64_t k = sd[s2].cnt[r];
+            if (k) MCHK(c, hipMemcpyPeerAsync(sd[r].d_recv + at * sizeof(KeyRec), c->p.device, sd[s2].d_send + soff * sizeof(KeyRec), cs[s2]->p.device, (size_t)k * sizeof(KeyRec), c->stream));
+            at += k;
+        }
+    }
+    uint64_t all_dups = 0;
+    for (uint32_t r = 0; r < world; ++r) {
+        mkt_ctx* c = cs[r];
+        MCHK(c, hipSetDevice(c->p.device));
+        MCHK(c, hipStreamSynchronize(c->stream));
+        uint64_t d = 0;
+        const int rc = mkt_ext_dedup_device(c, sd[r].d_recv, sd[r].nrecv, sd[r].d_flags, &d);
+        if (rc) { cleanup(); return rc; }
+        all_dups += d;
+    }
+    // one byte per record back to where the record came from
+    for (uint32_t s2 = 0; s2 < world; ++s2) {
+        mkt_ctx* c = cs[s2];
+        MCHK(c, hipSetDevice(c->p.device));
+        if (!sd[s2].n) { dups[s2] = 0; continue; }
+        MCHK(c, hipMalloc((void**)&sd[s2].d_back, (size_t)sd[s2].n));
+        uint64_t soff = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            uint64_t roff = 0;
+            for (uint32_t q = 0; q < s2; ++q) roff += sd[q].cnt[r];
+            const uint64_t k = sd[s2].cnt[r];
+            if (k) MCHK(c, hipMemcpyPeerAsync(sd[s2].d_back + soff, c->p.device, sd[r].d_flags + roff, cs[r]->p.device, (size_t)k, c->stream));
+            soff += k;
+        }
+        MCHK(c, hipStreamSynchronize(c->stream));
+        const int rc = mkt_ext_unpartition(c, sd[s2].d_back, flags ? flags[s2] : nullptr, flags_cap ? flags_cap[s2] : 0, &dups[s2]);
+        if (rc) { cleanup(); return rc; }
+    }
+#undef MCHK
+    cleanup();
+    uint64_t sum = 0;
+    for (uint32_t r = 0; r < world; ++r) sum += dups[r];
+    if (sum != all_dups) return fail(c0, MKT_E_KERNEL, "duplicate counts disagree after the exchange (%llu marked, %llu returned)", (unsigned long long)all_dups, (unsigned long long)sum);
+    return MKT_OK;
+}
 int mkt_ext_chrstat(mkt_ctx* c, int drop_last, char* out, size_t cap, size_t* len) {
     if (!c || !len) return MKT_E_ARG;
     if (!(c->p.extensions & MKT_EXT_KEYS)) return fail(c, MKT_E_STATE, "context created without MKT_EXT_KEYS");

@@ -35,7 +35,9 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <functional>
 #include "../../include/mkt.h"
+#include "sam2pairs_multi.h"
 
 int main(int argc, char* argv[]) {
     if (argc < 4) {     // sam2pairs.cpp:24-31
@@ -92,16 +94,32 @@ int main(int argc, char* argv[]) {
         if ((e = getenv("MKT_EXT_LANES")) && e[0] == '1') p.extensions |= MKT_EXT_LANES;
         p.ordered = 1;                 // .dedup.pairs pairs the lines with their duplicate flags by input order
     }
-    FILE* ftee = nullptr;              // extensions: the reported pairs once more, filtered into .dedup.pairs at the end
-    if (ext) {
-        ftee = fopen((base + ".dedup.pairs.tmp").c_str(), "wb+");
-        if (!ftee) { std::cerr << "Error: write dedup.pairs file failed!\n"; return 11; }
-    }
     const bool verbose = (e = getenv("MKT_VERBOSE")) && e[0] == '1';     // wall-clock marks on stderr (diagnostics only)
     const auto t_start = std::chrono::steady_clock::now();
     auto mark = [&](const char* what) {
         if (verbose) fprintf(stderr, "[mkt] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     };
+    // MKT_DEVICES=0,1,...: one shard of a regular input file per GPU (sam2pairs_multi.h); the same device twice = two contexts on it
+    if ((e = getenv("MKT_DEVICES")) && strchr(e, ',')) {
+        std::vector<int> devs;
+        for (const char* q = e; *q;) { devs.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        struct stat isb;
+        const bool in_regular = fstat(fileno(fin), &isb) == 0 && S_ISREG(isb.st_mode);
+        if (devs.size() > 16) { std::cerr << "Error: MKT_DEVICES: at most 16 devices\n"; return 2; }
+        if (!in_regular || getenv("MKT_SORTED")) std::cerr << "WARN: MKT_DEVICES needs a regular input file (and no MKT_SORTED): running on device " << devs[0] << " alone.\n", p.device = devs[0];
+        else {
+            const int mrc = multi::run(p, devs, fin, fsam, base, ext, verbose, mark);
+            if (mrc != 0) return mrc;
+            if ((e = getenv("MKT_CLEAN_EXIT")) && e[0] == '1') return 0;
+            fflush(stdout); fflush(stderr);
+            _exit(0);
+        }
+    }
+    FILE* ftee = nullptr;              // extensions: the reported pairs once more, filtered into .dedup.pairs at the end
+    if (ext) {
+        ftee = fopen((base + ".dedup.pairs.tmp").c_str(), "wb+");
+        if (!ftee) { std::cerr << "Error: write dedup.pairs file failed!\n"; return 11; }
+    }
     if (verbose) { (void)mkt_device_count(); mark("hip runtime up"); }
     mkt_ctx* ctx = nullptr;
     int rc = mkt_create(&p, &ctx);

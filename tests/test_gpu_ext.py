@@ -93,6 +93,44 @@ def test_executable_side_files(tmp_path):
     assert not (tmp_path / "o.unc.dedup.pairs.tmp").exists()
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_executable_on_several_devices_equals_one(tmp_path, devices):
+    """bin/sam2pairs with MKT_DEVICES (here the same GPU twice / three times = that many contexts on it): one contiguous shard of the
+    input file per context, cut on surviving-line group boundaries by the C++ host code; group offsets (quirk Q2), the input's end
+    on the last shard (quirk Q1), one .log.  With MKT_EXT=1 the duplicate keys are exchanged device to device inside the library
+    (mkt_ext_dedup_multi): .dups / .dedup.stat / .dedup.pairs / .chrstat and stdout (input order) equal the single-device run."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    import subprocess
+    texts = {"stress": (util.synth("stress", 63, 9000), "unc"), "dup": (_dup_heavy(6000, lanes=4) + util.synth("unc", 71, 3000, 100, "mm10", 4), "unc"),
+             "flash": (util.synth("flash", 64, 5000), "flash")}
+    for name, (text, mode) in texts.items():
+        inp = tmp_path / f"{name}.sam"
+        inp.write_bytes(text)
+        po, so, lo, st = util.oracle_run(text, mode, 8, 0.5, 10, True)
+        for ext in (False, True):
+            outs = {}
+            for tag, env in (("one", {}), ("multi", {"MKT_DEVICES": devices})):
+                e = dict(os.environ, MKT_BLOCK_MB="1", **env)
+                if ext:
+                    e.update(MKT_EXT="1", MKT_EXT_LANES="1")
+                pre = tmp_path / f"{name}_{tag}_{int(ext)}"
+                p = subprocess.run([m.exe_path(), str(inp), mode, str(pre), "8", "0.5", "10", "yes"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+                assert p.returncode == 0, (name, tag, p.stderr)
+                side = {sfx: (tmp_path / f"{name}_{tag}_{int(ext)}.{mode}{sfx}").read_bytes() for sfx in
+                        ([".sam", "2pairs.log"] + ([".dups", ".dedup.stat", ".dedup.pairs", ".chrstat"] if ext else []))}
+                outs[tag] = (p.stdout, side)
+            (o1, s1), (o2, s2) = outs["one"], outs["multi"]
+            assert s2["2pairs.log"] == s1["2pairs.log"] == lo, (name, ext)
+            assert util.canon(o2) == util.canon(o1) == util.canon(po), (name, ext)
+            assert util.canon(s2[".sam"]) == util.canon(s1[".sam"]) == util.canon(so), (name, ext)
+            if ext:
+                assert o2 == o1 == po                       # MKT_EXT=1: input order, over the shards as well
+                for sfx in (".dups", ".dedup.stat", ".dedup.pairs", ".chrstat"):
+                    assert s2[sfx] == s1[sfx], (name, sfx)
+                assert not list(tmp_path.glob("*.tmp*"))
+
+
 def test_sharded_dedup_equals_single_context():
     """Two contexts = two shards on one GPU; the key-space exchange is emulated with Python lists (bench / production
     pass RCCL all-gathers).  Flags must equal the single-context result; chromosome slots differ between the contexts
