@@ -241,6 +241,7 @@ typedef struct mkt_rmdup mkt_rmdup;
 int mkt_rmdup_create(int device, mkt_rmdup** out);
 void mkt_rmdup_destroy(mkt_rmdup* r);
 const char* mkt_rmdup_error(const mkt_rmdup* r);
+int mkt_rmdup_reserve(mkt_rmdup* r, size_t bytes);                   /* optional: room for that much FASTQ text up front (a regular file's size) */
 int mkt_rmdup_add(mkt_rmdup* r, const char* bytes, size_t n);       /* the next bytes of the FASTQ stream (host; copied) */
 int mkt_rmdup_run(mkt_rmdup* r, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved,
                   uint64_t stats[4] /* total, uniq, dup, discard */, uint64_t out_bytes[2]);

@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 #include <getopt.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include "../../include/mkt.h"
 
@@ -73,6 +74,13 @@ int main(int argc, char* argv[]) {
     mkt_rmdup* r = nullptr;
     int rc = mkt_rmdup_create(e ? atoi(e) : 0, &r);
     if (rc != MKT_OK) { std::cerr << "Error: GPU context: " << mkt_strerror(rc) << "\n"; return 20; }
+    {   // a regular file: its size once, instead of growing by doubling (old and new buffer side by side)
+        struct stat sb;
+        if (fstat(fileno(fin), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            rc = mkt_rmdup_reserve(r, (size_t)sb.st_size + 64);
+            if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_rmdup_error(r) << "\n"; return 21; }
+        }
+    }
     std::vector<char> buf((size_t)64 << 20);
     size_t k;
     while ((k = fread(buf.data(), 1, buf.size(), fin)) > 0) {

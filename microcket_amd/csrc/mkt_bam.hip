@@ -983,7 +983,17 @@ static int bam_reserve(mkt_bam* s, size_t need) {
     size_t ncap = s->cap ? s->cap : ((size_t)64 << 20);
     while (ncap < need) ncap *= 2;
     uint8_t* nb = nullptr;
-    BCHK(s, hipMalloc((void**)&nb, ncap + 64));
+    // (doubling keeps old and new side by side during the copy; when that does not fit: just enough; when that does not either, the
+    //  input is larger than one GPU takes -- text + records + compressed blocks are resident together, ~2.2 x the .sam: INTEGRATION.md)
+    hipError_t e = hipMalloc((void**)&nb, ncap + 64);
+    if (e != hipSuccess) { (void)hipGetLastError(); ncap = need + ((size_t)64 << 20); e = hipMalloc((void**)&nb, ncap + 64); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        return bfail(s, MKT_E_NOMEM, "the SAM input (%.1f GB so far) does not fit this GPU (%.1f of %.1f GB free): sam2bam keeps the whole input in HBM "
+                     "(samtools sort spills to disk instead); convert the modes' .sam files one by one", (double)need / 1e9, (double)fr / 1e9, (double)tot / 1e9);
+    }
     if (s->d_text) {
         BCHK(s, hipStreamSynchronize(s->stream));
         if (s->len) BCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice));

@@ -284,6 +284,7 @@ static void set_dims_from_avg(mkt_ctx* c, double bytes_per_line) {
     c->dims_probed = true;
     if (c->cfg == CFG_SMALL || c->p.tiles != MKT_TILES_AUTO) return;
     c->dims = lean_dims(bytes_per_line);
+    if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "tile geometry: %.1f bytes per line -> tile %u, halos %u / %u\n", bytes_per_line, c->dims.tile, c->dims.hb, c->dims.hf);
 }
 static bool shrink_dims(mkt_ctx* c) {
     if (c->cfg == CFG_SMALL || c->dims.tile <= 2048u) return false;

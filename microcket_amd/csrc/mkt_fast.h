@@ -29,20 +29,23 @@ namespace mkt {
 constexpr int kLeanGeom[4] = {MKT_LEAN_GEOM};
 constexpr int kLeanTile = kLeanGeom[0], kLeanHB = kLeanGeom[1], kLeanHF = kLeanGeom[2], kLeanLCAP = kLeanGeom[3];
 #else
-constexpr int kLeanTile = 49152, kLeanHB = 3072, kLeanHF = 3072, kLeanLCAP = 168;
+constexpr int kLeanTile = 49152, kLeanHB = 3072, kLeanHF = 4096, kLeanLCAP = 168;
 #endif
 constexpr int kMidTile = 32768, kMidHB = 2048, kMidHF = 3072, kMidLCAP = 160;            // (emulation configs)
 constexpr int kDenseTile = 16384, kDenseHB = 1024, kDenseHF = 2048, kDenseLCAP = 160;
 constexpr int kLeanLinesTarget = 126;      // lines per window the host aims at: measured 122 / 126 / 129 / 132 -> 0.838 / 0.819 / 0.819 / 0.868 ms per block at 150 bp (fewer tiles against more windows past 128 lines)
 
-// tile dimensions for text of `avg` bytes per line: ~kLeanLinesTarget lines per window, a back halo of ~5 lines (the previous
-// surviving line), a forward halo of ~7.5 lines (the rest of the last group), all within the kernel's capacities
+// tile dimensions for text of `avg` bytes per line: ~kLeanLinesTarget lines per window, a back halo of ~7.5 lines (the previous
+// surviving line) and a forward halo of ~8.75 (the rest of the last group and the first surviving line of the next one), all within
+// the kernel's capacities.  Halos are sized by what a deferred tile costs: a pass of the generic kernel takes 0.1 - 0.2 ms for a
+// handful of tiles, a tenth of a block's time.  Measured on the bench data: back 5 / forward 7.5 lines: one tile in 21 000
+// deferred (two per 2 GB block); 7.5 / 7.5: one in 170 000 (all "group open at the end of the window").
 MKT_HD TileDims lean_dims(double avg) {
     if (avg < 48.0) avg = 48.0;
     if (avg > 4096.0) avg = 4096.0;
     auto r16 = [](double x) { return ((uint32_t)x + 15u) & ~15u; };
     TileDims d;
-    d.hb = r16(5.0 * avg); d.hf = r16(7.5 * avg);
+    d.hb = r16(7.5 * avg); d.hf = r16(8.75 * avg);
     if (d.hb < 256u) d.hb = 256u;
     if (d.hb > (uint32_t)kLeanHB) d.hb = (uint32_t)kLeanHB;
     if (d.hf < 512u) d.hf = 512u;

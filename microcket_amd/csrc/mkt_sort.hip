@@ -785,18 +785,39 @@ void mkt_rmdup_destroy(mkt_rmdup* s) {
 }
 const char* mkt_rmdup_error(const mkt_rmdup* s) { return s ? s->err.c_str() : ""; }
 
+// room for `need` bytes of FASTQ text.  The whole input is resident while it is worked on (the duplicate keys are global): growing
+// doubles the buffer -- old and new coexist during the copy -- and falls back to just enough when the doubled size does not fit;
+// what still does not fit is an input larger than one GPU takes (~40 % of the HBM for a pipe of unknown length,
+// ~45 % for a regular file, whose size is reserved once)
+static int rmdup_room(mkt_rmdup* s, size_t need) {
+    if (need <= s->cap) return MKT_OK;
+    size_t ncap = s->cap ? s->cap : ((size_t)256 << 20);
+    while (ncap < need) ncap *= 2;
+    uint8_t* nb = nullptr;
+    hipError_t e = hipMalloc((void**)&nb, ncap + 64);
+    if (e != hipSuccess) { (void)hipGetLastError(); ncap = need + ((size_t)64 << 20); e = hipMalloc((void**)&nb, ncap + 64); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        return rfail(s, MKT_E_NOMEM, "the FASTQ input (%.1f GB so far) does not fit this GPU next to what is resident (%.1f of %.1f GB free): "
+                     "krmdup keeps the whole input in HBM; split the lanes (the driver's -b) or the file", (double)need / 1e9, (double)fr / 1e9, (double)tot / 1e9);
+    }
+    if (s->d_text) { if (s->len) RCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice)); RCHK(s, hipFree(s->d_text)); }
+    s->d_text = nb; s->cap = ncap;
+    return MKT_OK;
+}
+int mkt_rmdup_reserve(mkt_rmdup* s, size_t bytes) {
+    if (!s) return MKT_E_ARG;
+    if (s->done) return rfail(s, MKT_E_STATE, "reserve after run");
+    RCHK(s, hipSetDevice(s->device));
+    return rmdup_room(s, bytes + 1);
+}
 int mkt_rmdup_add(mkt_rmdup* s, const char* bytes, size_t n) {
     if (!s || (n && !bytes)) return MKT_E_ARG;
     if (s->done) return rfail(s, MKT_E_STATE, "add after run");
     RCHK(s, hipSetDevice(s->device));
-    if (s->len + n + 1 > s->cap) {
-        size_t ncap = s->cap ? s->cap : ((size_t)256 << 20);
-        while (ncap < s->len + n + 1) ncap *= 2;
-        uint8_t* nb = nullptr;
-        RCHK(s, hipMalloc((void**)&nb, ncap + 64));
-        if (s->d_text) { if (s->len) RCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice)); RCHK(s, hipFree(s->d_text)); }
-        s->d_text = nb; s->cap = ncap;
-    }
+    { const int rc = rmdup_room(s, s->len + n + 1); if (rc) return rc; }
     if (n) RCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes, n, hipMemcpyHostToDevice, s->stream));
     RCHK(s, hipStreamSynchronize(s->stream));
     s->len += n;
