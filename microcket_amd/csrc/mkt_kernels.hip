@@ -1111,55 +1111,16 @@ __global__ void k_dd_init(const KeyRec* keys, uint64_t n, uint64_t* rec) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
         rec[j] = (mix64(keys[j].k0 ^ mix64(keys[j].k1 & kKeyMask1)) & 0xFFFFFFFF00000000ull) | j;
 }
-// 8-bit digits.  Every WAVE of a workgroup is a block of its own: a contiguous share of the records, a private 256-bin table in
-// LDS, no barrier inside the pass.  Ranking inside a wave is a match on the digit: eight ballots give every lane the mask of
-// the lanes that hold its digit (its rank = the set bits below it, the run's size = all of them); the first lane of a run
-// advances the wave's cursor for that digit.  Stable: shares, 64-record steps and lanes are all in input order.
-constexpr int DD_WAVES = DD_WG / 64;
-__device__ inline uint64_t digit_peers(uint32_t d, bool live) {
-    uint64_t m = __ballot(live);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const uint64_t v = __ballot(live && ((d >> b) & 1u));
-        m &= ((d >> b) & 1u) ? v : ~v;
-    }
-    return m;
+__global__ __launch_bounds__(DD_WG) void k_dd_hist(const uint64_t* rec, uint64_t n, uint64_t per, int shift, uint32_t* hist, uint32_t G) {
+    __shared__ uint32_t cnt[16];
+    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j = b + threadIdx.x; j < e; j += DD_WG) atomicAdd(&cnt[(rec[j] >> shift) & 15u], 1u);
+    __syncthreads();
+    if (threadIdx.x < 16) hist[threadIdx.x * G + blockIdx.x] = cnt[threadIdx.x];
 }
-__global__ __launch_bounds__(DD_WG) void k_dd_hist(const uint64_t* rec, uint64_t n, uint64_t per, int shift, uint64_t* hist, uint32_t GW) {
-    __shared__ uint32_t cnt[DD_WAVES][256];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int k = lane; k < 256; k += 64) cnt[wv][k] = 0;
-    const uint32_t blk = blockIdx.x * DD_WAVES + wv;                 // this wave's block
-    const uint64_t b = (uint64_t)blk * per, e = b + per < n ? b + per : n;
-    for (uint64_t j0 = b; j0 < e; j0 += 64) {
-        const uint64_t j = j0 + lane;
-        const bool live = j < e;
-        const uint32_t d = live ? (uint32_t)((rec[j] >> shift) & 255u) : 0u;
-        const uint64_t m = digit_peers(d, live);
-        if (live && !(m & ((1ull << lane) - 1ull))) cnt[wv][d] += (uint32_t)__popcll(m);      // first lane of the run (one writer per digit)
-    }
-    for (int k = lane; k < 256; k += 64) hist[(uint64_t)k * GW + blk] = cnt[wv][k];
-}
-__global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* rec, uint64_t n, uint64_t per, int shift, const uint64_t* hist, uint32_t GW, uint64_t* rec2) {
-    __shared__ uint32_t base[DD_WAVES][256];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t blk = blockIdx.x * DD_WAVES + wv;
-    for (int k = lane; k < 256; k += 64) base[wv][k] = (uint32_t)hist[(uint64_t)k * GW + blk];
-    const uint64_t b = (uint64_t)blk * per, e = b + per < n ? b + per : n;
-    for (uint64_t j0 = b; j0 < e; j0 += 64) {
-        const uint64_t j = j0 + lane;
-        const bool live = j < e;
-        const uint64_t rv = live ? rec[j] : 0;
-        const uint32_t d = live ? (uint32_t)((rv >> shift) & 255u) : 0u;
-        const uint64_t m = digit_peers(d, live);
-        const uint32_t rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        uint32_t o = 0;
-        if (live) o = base[wv][d] + rank;                            // (every lane of the run reads the cursor before its first lane moves it)
-        if (live && rank == 0) base[wv][d] += (uint32_t)__popcll(m);
-        if (live) rec2[o] = rv;
-    }
-}
-__global__ __launch_bounds__(NT) void k_dd_scan(uint32_t* hist, uint32_t m) {       // exclusive scan of m counters, one workgroup (the partition's few counters)
+__global__ __launch_bounds__(NT) void k_dd_scan(uint32_t* hist, uint32_t m) {       // exclusive scan of m counters, one workgroup
     __shared__ ScanScratch sc;
     __shared__ uint64_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -1171,6 +1132,36 @@ __global__ __launch_bounds__(NT) void k_dd_scan(uint32_t* hist, uint32_t m) {   
         if (i < m) hist[i] = (uint32_t)(carry + e);
         __syncthreads();
         if (threadIdx.x == 0) carry += tx;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(DD_WG) void k_dd_scatter(const uint64_t* rec, uint64_t n, uint64_t per, int shift, const uint32_t* hist, uint32_t G, uint64_t* rec2) {
+    __shared__ uint32_t base[16];
+    __shared__ uint32_t wcnt[DD_WG / 64][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < 16) base[tid] = hist[tid * G + blockIdx.x];
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * per, e = b + per < n ? b + per : n;
+    for (uint64_t j0 = b; j0 < e; j0 += DD_WG) {            // sub-tiles in input order keep the pass stable
+        const uint64_t j = j0 + tid;
+        const bool live = j < e;
+        const uint64_t rv = live ? rec[j] : 0;
+        const uint32_t d = live ? (uint32_t)((rv >> shift) & 15u) : 16u;
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t dd = 0; dd < 16; ++dd) {
+            const uint64_t m = __ballot(d == dd);
+            if (d == dd) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[wv][dd] = __popcll(m);
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t o = base[d] + rank;
+            for (int w = 0; w < wv; ++w) o += wcnt[w][d];
+            rec2[o] = rv;
+        }
+        __syncthreads();
+        if (tid < 16) { uint32_t s = 0; for (int w = 0; w < DD_WG / 64; ++w) s += wcnt[w][tid]; base[tid] += s; }
         __syncthreads();
     }
 }
@@ -1194,9 +1185,9 @@ __global__ void k_dd_mark(const KeyRec* keys, const uint64_t* rec, uint64_t n, u
     if (mine) atomicAdd((unsigned long long*)&res->dups, (unsigned long long)mine);
     if (blockIdx.x == 0 && threadIdx.x == 0) res->total = n;
 }
-constexpr uint32_t kDdMaxBlocks = 2048;                                  // wave blocks of a pass (512 workgroups)
 size_t dedup_work_bytes(uint64_t n) {
-    return (size_t)(n * (8 + 8) + (size_t)256 * kDdMaxBlocks * 8 + 8192);
+    const uint64_t G = 1024;
+    return (size_t)(n * (8 + 8) + 16 * G * 4 + 4096);
 }
 hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* work, size_t work_bytes, DedupResult* d_res, hipStream_t s) {
     hipError_t e = hipMemsetAsync(d_res, 0, sizeof(DedupResult), s);
@@ -1205,25 +1196,23 @@ hipError_t launch_dedup(const KeyRec* keys, uint64_t n, uint8_t* flags, void* wo
     uint8_t* w = (uint8_t*)work;
     uint64_t* rA = (uint64_t*)w; w += n * 8;
     uint64_t* rB = (uint64_t*)w; w += n * 8;
-    uint64_t* hist = (uint64_t*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
-    // wave blocks of >= 2048 records (32 steps of 64), at most kDdMaxBlocks: 256 x GW counters per pass, digit-major
-    uint32_t GW = (uint32_t)((n + 2047) / 2048);
-    if (GW > kDdMaxBlocks) GW = kDdMaxBlocks;
-    GW = (GW + DD_WAVES - 1) / DD_WAVES * DD_WAVES;
-    const uint64_t per = (n + GW - 1) / GW;
-    int bits = 2;                                             // log2(n) + 2, in whole digits, 16 .. 32
+    uint32_t* hist = (uint32_t*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+    uint32_t G = (uint32_t)((n + 8191) / 8192);
+    if (G > 1024) G = 1024;
+    if (G == 0) G = 1;
+    const uint64_t per = (n + G - 1) / G;
+    int bits = 2;                                             // log2(n) + 2, in whole digits, 12 .. 32
     while (bits < 34 && (1ull << (bits - 2)) < n) ++bits;
-    bits = bits < 16 ? 16 : (bits > 32 ? 32 : bits);
-    const int passes = (bits + 7) / 8;
+    bits = bits < 12 ? 12 : (bits > 32 ? 32 : bits);
+    const int passes = (bits + 3) / 4;
     hipLaunchKernelGGL(k_dd_init, dim3(1024), dim3(256), 0, s, keys, n, rA);
     for (int p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(k_dd_hist, dim3(GW / DD_WAVES), dim3(DD_WG), 0, s, (const uint64_t*)rA, n, per, 32 + 8 * p, hist, GW);
-        e = launch_exscan(hist, (uint64_t)256 * GW, hist + (uint64_t)256 * GW, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_dd_scatter, dim3(GW / DD_WAVES), dim3(DD_WG), 0, s, (const uint64_t*)rA, n, per, 32 + 8 * p, (const uint64_t*)hist, GW, rB);
+        hipLaunchKernelGGL(k_dd_hist, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)rA, n, per, 32 + 4 * p, hist, G);
+        hipLaunchKernelGGL(k_dd_scan, dim3(1), dim3(NT), 0, s, hist, 16u * G);
+        hipLaunchKernelGGL(k_dd_scatter, dim3(G), dim3(DD_WG), 0, s, (const uint64_t*)rA, n, per, 32 + 4 * p, (const uint32_t*)hist, G, rB);
         uint64_t* t = rA; rA = rB; rB = t;
     }
-    const uint64_t run_mask = ((passes * 8 >= 32 ? 0xFFFFFFFFull : ((1ull << (passes * 8)) - 1ull))) << 32;
+    const uint64_t run_mask = ((passes * 4 >= 32 ? 0xFFFFFFFFull : ((1ull << (passes * 4)) - 1ull))) << 32;
     e = hipMemsetAsync(flags, 0, n, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_dd_mark, dim3(1024), dim3(256), 0, s, keys, (const uint64_t*)rA, n, run_mask, flags, d_res);
