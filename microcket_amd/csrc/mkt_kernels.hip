@@ -678,6 +678,24 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
         }
         __syncthreads();
         STAMP(10);
+#if defined(MKT_STAMPS)
+        // diagnostic (debug_stop 10): what a kernel that ENDS here would cost -- the front half of a split into "parse" and "classify +
+        // emit" kernels.  Every own line leaves a 32-byte record (in the .sam buffer: run it with the .sam output on), the scan of the
+        // next window goes on as usual.  Outputs are wrong.
+        if (a.debug_stop == 10) {
+            if (a.out.sam && !st.abn) for (uint32_t i = first_idx + (uint32_t)tid; i < end_idx; i += NTW) {
+                const uint4 r0 = make_uint4(st.rc.f.pos[i], st.rc.f.lclip[i] | (st.rc.f.rclip[i] << 16), st.rc.f.mappable[i] | ((uint32_t)st.flag[i] << 16), st.rc.f.right0[i]);
+                const uint4 r1 = make_uint4(st.rc.f.left1[i], st.rc.f.right1[i], G.w0 + st.goff[i], st.qn_len[i] | ((uint32_t)st.rn_off[i] << 8) | ((uint32_t)st.rn_len[i] << 16) | ((uint32_t)st.bits[i] << 24));
+                uint4* d = reinterpret_cast<uint4*>(a.out.sam + ((size_t)t * Cfg::LCAP + i) * 32u);
+                if (((size_t)t * Cfg::LCAP + i) * 32u + 32u <= a.out.sam_cap) { d[0] = r0; d[1] = r1; }
+            }
+            if (NSW && wave >= (uint32_t)(NWV - NSW) && t + gdim < a.ntiles)
+                fast_scan<Cfg, (NSW ? NSW : 1)>(a, t + gdim, s_hit[cur ^ 1u], wave - (uint32_t)(NWV - NSW), lpt_a, own(wave - (uint32_t)(NWV - NSW), NSW, lpt_sw), tid & 63);
+            if (NSW && t + gdim < a.ntiles) { scanned = true; cur ^= 1u; }
+            __syncthreads();
+            continue;
+        }
+#endif
         if (!st.abn) for (uint32_t i = first_idx + rr_id; i < end_idx; i += 64 * RR) fast_group(st, tv, P, G, i);
         // the scanning waves: the rest of the next tile's window
         if (NSW && wave >= (uint32_t)(NWV - NSW) && t + gdim < a.ntiles)
