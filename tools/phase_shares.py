@@ -1,7 +1,7 @@
 """Diagnostic: per-phase shader-clock shares of the fused tile kernel (stamp build, never shipped).
 
     python -c "from microcket_amd import build; build.build_stamps_lib()"
-    MKT_LIB=microcket_amd/libmkt_hip_stamps.so python tools/phase_shares.py [pairs] [yes|no]
+    MKT_LIB=microcket_amd/libmkt_hip_stamps.so python tools/phase_shares.py [pairs] [yes|no] [read_len]
 """
 import ctypes as C
 import os
@@ -17,7 +17,8 @@ ORDER = [1, 2, 9, 3, 10, 4, 6, 11, 8]
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 sam = len(sys.argv) > 2 and sys.argv[2] == "yes"
 ctx = m.Context("unc", 0.5, 10, sam, 8, device=0, tiles=m.TILES_AUTO if os.environ.get("MKT_TILES") == "auto" else m.TILES_FAST, extensions=m.EXT_KEYS if os.environ.get("MKT_PROBE_EXT") else 0)
-ds = ctx.dataset(20260105, 0, pairs, 1 << 21)
+read_len = int(sys.argv[3]) if len(sys.argv) > 3 else 150
+ds = ctx.dataset(20260105, 0, pairs, 1 << 21, read_len=read_len)
 ctx.L.mkt_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 out = (C.c_ulonglong * 16)()
 for _ in range(2):

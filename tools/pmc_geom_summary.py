@@ -2,7 +2,7 @@
 import collections, csv, glob, os, sys
 out = sys.argv[1]
 rows = collections.defaultdict(dict)
-for d in sorted(glob.glob(os.path.join(out, "[ab]_*"))):
+for d in sorted(glob.glob(os.path.join(out, "[abcd]_*"))):
     if not os.path.isdir(d):
         continue
     tag = os.path.basename(d)[2:]
