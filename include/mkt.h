@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MKT_ABI_VERSION 8
+#define MKT_ABI_VERSION 9
 
 enum { MKT_MODE_FLASH = 0, MKT_MODE_UNC = 1 };           /* argv[2], sam2pairs.cpp:59-67 */
 
@@ -241,7 +241,16 @@ typedef struct mkt_rmdup mkt_rmdup;
 int mkt_rmdup_create(int device, mkt_rmdup** out);
 void mkt_rmdup_destroy(mkt_rmdup* r);
 const char* mkt_rmdup_error(const mkt_rmdup* r);
-int mkt_rmdup_reserve(mkt_rmdup* r, size_t bytes);                   /* optional: room for that much FASTQ text up front (a regular file's size) */
+/* STREAMING form (what bin/krmdup[.pipe] use; any input size): begin, then push the bytes as they arrive.  The input is worked off in
+ * SEGMENTS of whole 2^16-pair batches -- the reference's own batches (krmdup.cpp:19, 330-364), so the output order is the reference's --
+ * as soon as MKT_RMDUP_SEGMENT_MB (default 256) of text are buffered: only that much FASTQ text is resident, plus 9 bytes per read pair
+ * seen so far (its key and bucket) and a hash set of pair ordinals (4 bytes per slot, load <= 1/2) -- "first seen wins" holds across
+ * segments.  A push that worked off a segment reports what it left in the outputs (out_bytes; fetch before the next push). */
+int mkt_rmdup_begin(mkt_rmdup* r, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved);
+int mkt_rmdup_push(mkt_rmdup* r, const char* bytes, size_t n, int final, uint64_t out_bytes[2]);
+int mkt_rmdup_stats(const mkt_rmdup* r, uint64_t stats[4] /* total, uniq, dup, discard so far */);
+/* RESIDENT form (inputs that fit HBM; kept for callers of ABI <= 8): add everything, then run = ONE segment over all of it */
+int mkt_rmdup_reserve(mkt_rmdup* r, size_t bytes);                   /* optional: room for that much FASTQ text up front */
 int mkt_rmdup_add(mkt_rmdup* r, const char* bytes, size_t n);       /* the next bytes of the FASTQ stream (host; copied) */
 int mkt_rmdup_run(mkt_rmdup* r, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved,
                   uint64_t stats[4] /* total, uniq, dup, discard */, uint64_t out_bytes[2]);

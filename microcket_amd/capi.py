@@ -18,6 +18,7 @@ EXPORTS = [
     "mkt_reset", "mkt_ext_dedup", "mkt_ext_chrstat", "mkt_ext_chr_names", "mkt_ext_keys_fetch", "mkt_ext_dedup_keys", "mkt_ext_keys_device", "mkt_ext_partition", "mkt_ext_dedup_device", "mkt_ext_unpartition", "mkt_ext_dedup_multi", "mkt_dataset_create", "mkt_dataset_info", "mkt_dataset_block", "mkt_dataset_destroy", "mkt_group_count",
     "mkt_sorter_create", "mkt_sorter_destroy", "mkt_sorter_error", "mkt_sorter_add", "mkt_sorter_add_device", "mkt_sorter_sort", "mkt_sorter_fetch",
     "mkt_rmdup_create", "mkt_rmdup_destroy", "mkt_rmdup_error", "mkt_rmdup_reserve", "mkt_rmdup_add", "mkt_rmdup_run", "mkt_rmdup_fetch",
+    "mkt_rmdup_begin", "mkt_rmdup_push", "mkt_rmdup_stats",
     "mkt_bam_create", "mkt_bam_destroy", "mkt_bam_error", "mkt_bam_note", "mkt_bam_add", "mkt_bam_add_device", "mkt_bam_run", "mkt_bam_fetch",
     "mkt_bam_reserve", "mkt_bam_window", "mkt_bam_commit", "mkt_bam_read",
 ]
@@ -154,6 +155,9 @@ def load_library():
     L.mkt_rmdup_add.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
     L.mkt_rmdup_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.mkt_rmdup_fetch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_size_t]
+    L.mkt_rmdup_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.mkt_rmdup_push.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64)]
+    L.mkt_rmdup_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.mkt_bam_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.mkt_bam_destroy.argtypes = [C.c_void_p]
     L.mkt_bam_destroy.restype = None
@@ -500,32 +504,51 @@ class PairsSorter:
         self.close()
 
 
-def rmdup(text: bytes, hskip1=5, keylen1=16, hskip2=5, keylen2=16, interleaved=False, device=0, piece=1 << 24):
-    """The reference's krmdup on the GPU (mkt_rmdup_*): returns (read1 | interleaved bytes, read2 bytes, (total, uniq, dup, discard))."""
+def rmdup(text: bytes, hskip1=5, keylen1=16, hskip2=5, keylen2=16, interleaved=False, device=0, piece=1 << 24, stream=False):
+    """The reference's krmdup on the GPU (mkt_rmdup_*): returns (read1 | interleaved bytes, read2 bytes, (total, uniq, dup, discard)).
+    stream=False: everything added, then ONE run (the resident form).  stream=True: begin / push piece by piece / push(final), the
+    outputs of every segment taken as they come (MKT_RMDUP_SEGMENT_MB sets the segment size; what bin/krmdup does)."""
     L = load_library()
     h = C.c_void_p()
     rc = L.mkt_rmdup_create(device, C.byref(h))
     if rc != 0:
         raise MktError(f"mkt_rmdup_create: {L.mkt_strerror(rc).decode()}")
+
+    def fetch(ob, outs):
+        for which in (0, 1):
+            if ob[which]:
+                buf = C.create_string_buffer(ob[which])
+                rc = L.mkt_rmdup_fetch(h, which, 0, buf, ob[which])
+                if rc != 0:
+                    raise MktError(f"mkt_rmdup_fetch: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+                outs[which].append(buf.raw[:ob[which]])
+
     try:
-        for k in range(0, len(text), piece):
-            part = text[k:k + piece]
-            rc = L.mkt_rmdup_add(h, part, len(part))
-            if rc != 0:
-                raise MktError(f"mkt_rmdup_add: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
         st = (C.c_uint64 * 4)()
         ob = (C.c_uint64 * 2)()
-        rc = L.mkt_rmdup_run(h, hskip1, keylen1, hskip2, keylen2, 1 if interleaved else 0, st, ob)
-        if rc != 0:
-            raise MktError(f"mkt_rmdup_run: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
-        outs = []
-        for which in (0, 1):
-            buf = C.create_string_buffer(max(ob[which], 1))
-            rc = L.mkt_rmdup_fetch(h, which, 0, buf, ob[which])
+        outs = ([], [])
+        if stream:
+            rc = L.mkt_rmdup_begin(h, hskip1, keylen1, hskip2, keylen2, 1 if interleaved else 0)
             if rc != 0:
-                raise MktError(f"mkt_rmdup_fetch: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
-            outs.append(buf.raw[:ob[which]])
-        return outs[0], outs[1], tuple(int(x) for x in st)
+                raise MktError(f"mkt_rmdup_begin: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+            for k in list(range(0, len(text), piece)) + [None]:
+                part = b"" if k is None else text[k:k + piece]
+                rc = L.mkt_rmdup_push(h, part, len(part), 1 if k is None else 0, ob)
+                if rc != 0:
+                    raise MktError(f"mkt_rmdup_push: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+                fetch(ob, outs)
+            L.mkt_rmdup_stats(h, st)
+        else:
+            for k in range(0, len(text), piece):
+                part = text[k:k + piece]
+                rc = L.mkt_rmdup_add(h, part, len(part))
+                if rc != 0:
+                    raise MktError(f"mkt_rmdup_add: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+            rc = L.mkt_rmdup_run(h, hskip1, keylen1, hskip2, keylen2, 1 if interleaved else 0, st, ob)
+            if rc != 0:
+                raise MktError(f"mkt_rmdup_run: {L.mkt_strerror(rc).decode()}: {L.mkt_rmdup_error(h).decode()}")
+            fetch(ob, outs)
+        return b"".join(outs[0]), b"".join(outs[1]), tuple(int(x) for x in st)
     finally:
         L.mkt_rmdup_destroy(h)
 

@@ -1,9 +1,10 @@
 // krmdup_main.cpp -- drop-in for the reference's bin/krmdup and bin/krmdup.pipe (src/preprocess/krmdup.cpp, krmdup.pipe.cpp):
 // same options, same files (<prefix>.read1.fq / .read2.fq appended, or interleaved FASTQ on stdout when the executable is
 // called krmdup.pipe), same <prefix>.log lines, same exit codes.  The duplicate removal itself runs on the GPU behind
-// mkt_rmdup_* (include/mkt.h); this file only moves bytes.  The whole input is taken in before the first read leaves
-// (the key set is global; the reference streams batch by batch): the driver's pipe `ktrim | krmdup.pipe | flash`
-// (microcket:405-408) works unchanged, flash just starts later.
+// mkt_rmdup_* (include/mkt.h); this file only moves bytes.  Like the reference the input streams through: it is worked off
+// in segments of whole 2^16-pair batches (MKT_RMDUP_SEGMENT_MB of text each, default 256 MiB) against a key set that stays on the
+// device, and every segment's reads leave before the next one is read -- any input size, and in the driver's pipe
+// `ktrim | krmdup.pipe | flash` (microcket:405-408) flash gets its first reads after the first segment.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -74,30 +75,31 @@ int main(int argc, char* argv[]) {
     mkt_rmdup* r = nullptr;
     int rc = mkt_rmdup_create(e ? atoi(e) : 0, &r);
     if (rc != MKT_OK) { std::cerr << "Error: GPU context: " << mkt_strerror(rc) << "\n"; return 20; }
-    {   // a regular file: its size once, instead of growing by doubling (old and new buffer side by side)
-        struct stat sb;
-        if (fstat(fileno(fin), &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
-            rc = mkt_rmdup_reserve(r, (size_t)sb.st_size + 64);
-            if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_rmdup_error(r) << "\n"; return 21; }
-        }
-    }
+    rc = mkt_rmdup_begin(r, hskip1, keylen1, hskip2, keylen2, pipe ? 1 : 0);
+    if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_rmdup_error(r) << "\n"; return 21; }
     std::vector<char> buf((size_t)64 << 20);
+    uint64_t ob[2];
+    auto drain = [&]() -> bool {                                    // what the last push left in the outputs
+        for (int which = 0; which < (pipe ? 1 : 2); ++which) {
+            const int fd = pipe ? 1 : fileno(which ? f2 : f1);
+            for (uint64_t off = 0; off < ob[which]; off += buf.size()) {
+                const size_t n = ob[which] - off < buf.size() ? (size_t)(ob[which] - off) : buf.size();
+                if (mkt_rmdup_fetch(r, which, off, buf.data(), n) != MKT_OK || !write_all(fd, buf.data(), n)) return false;
+            }
+        }
+        return true;
+    };
     size_t k;
-    while ((k = fread(buf.data(), 1, buf.size(), fin)) > 0) {
-        rc = mkt_rmdup_add(r, buf.data(), k);
+    for (;;) {
+        k = fread(buf.data(), 1, buf.size(), fin);
+        rc = mkt_rmdup_push(r, buf.data(), k, k == 0 ? 1 : 0, ob);
         if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_rmdup_error(r) << "\n"; return 21; }
+        if ((ob[0] | ob[1]) && !drain()) { std::cerr << "Error: write output failed!\n"; return 22; }
+        if (k == 0) break;
     }
     fclose(fin);
-    uint64_t st[4], ob[2];
-    rc = mkt_rmdup_run(r, hskip1, keylen1, hskip2, keylen2, pipe ? 1 : 0, st, ob);
-    if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_rmdup_error(r) << "\n"; return 21; }
-    for (int which = 0; which < (pipe ? 1 : 2); ++which) {
-        const int fd = pipe ? 1 : fileno(which ? f2 : f1);
-        for (uint64_t off = 0; off < ob[which]; off += buf.size()) {
-            const size_t n = ob[which] - off < buf.size() ? (size_t)(ob[which] - off) : buf.size();
-            if (mkt_rmdup_fetch(r, which, off, buf.data(), n) != MKT_OK || !write_all(fd, buf.data(), n)) { std::cerr << "Error: write output failed!\n"; return 22; }
-        }
-    }
+    uint64_t st[4];
+    mkt_rmdup_stats(r, st);
     if (f1) fclose(f1);
     if (f2) fclose(f2);
     std::ofstream flog((std::string(outprefix) + ".log").c_str(), std::ios::app);      // krmdup.cpp:368-390

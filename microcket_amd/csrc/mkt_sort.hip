@@ -620,14 +620,15 @@ namespace mkt {
 struct RmParams { uint32_t hskip1, epos1, hskip2, epos2; };
 constexpr uint32_t RM_BATCH = 1u << 16;                      // krmdup.cpp:19
 
-// one record per pair: hi = key, lo = bucket (0 A, 1 C, 2 G, 3 everything else; 4 = discarded), idx = pair
-__global__ void k_rm_keys(const uint8_t* text, const uint64_t* starts, uint64_t npairs, RmParams P, SortRec* rec) {
+// per pair: its key and its bucket (0 A, 1 C, 2 G, 3 everything else; 4 = discarded).  ord0 = ordinal of the segment's first pair
+// in the whole input: keys are kept by ordinal for as long as the run lasts (the hash table below refers to them)
+__global__ void k_rm_keys(const uint8_t* text, const uint64_t* starts, uint64_t npairs, RmParams P, uint64_t ord0, uint64_t* keys, uint8_t* bucket /* both by ordinal */) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= npairs) return;
     const uint64_t s1 = starts[8 * r + 1], l1 = starts[8 * r + 2] - 1 - s1;      // seq1 without its newline
     const uint64_t s2 = starts[8 * r + 5], l2 = starts[8 * r + 6] - 1 - s2;
-    SortRec o;
-    o.hi = 0; o.lo = 4; o.idx = (uint32_t)r;
+    uint64_t okey = 0;
+    uint8_t ob = 4;
     uint8_t first = 'N';
     if (l1 >= P.epos1) first = text[s1 + P.hskip1];                              // krmdup.cpp:105-108
     if (first != 'N' && l2 >= P.epos2) {                                         // :110 / :157
@@ -643,25 +644,76 @@ __global__ void k_rm_keys(const uint8_t* text, const uint64_t* starts, uint64_t 
         };
         for (uint32_t i = P.hskip1; i != P.epos1; ++i) key = (key << 2) | code(text[s1 + i]);
         for (uint32_t i = P.hskip2; i != P.epos2; ++i) key = (key << 2) | code(text[s2 + i]);
-        if (!bad) { o.hi = key; o.lo = first == 'A' ? 0u : (first == 'C' ? 1u : (first == 'G' ? 2u : 3u)); }
+        if (!bad) { okey = key; ob = first == 'A' ? 0u : (first == 'C' ? 1u : (first == 'G' ? 2u : 3u)); }
     }
-    rec[r] = o;
+    keys[ord0 + r] = okey;
+    bucket[ord0 + r] = ob;
 }
-// after the stable sort by (bucket, key): the first record of a run stays.  state[pair]: 0 discarded, 1 duplicate, 2 + bucket kept
-__global__ void k_rm_mark(const SortRec* rec, uint64_t n, uint8_t* state, unsigned long long* counts /* uniq, dup, discard */) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// The set of keys seen so far (krmdup.cpp:325 keeps one std::unordered_set per bucket; the bucket is a function of the key's first
+// base unless that base is lower case or not one of ACGT -- so the set here is over (bucket, key)): an open-addressing table of pair
+// ORDINALS, the keys themselves stay in keys[].  A slot is claimed with one compare-and-swap; a pair that finds its own (bucket, key)
+// in a slot leaves the SMALLER ordinal there (atomicMin), so "the first one seen wins" whatever order the lanes run in, and pairs of
+// earlier segments (smaller ordinals) always win against later ones.  Load <= 1/2: a probe sequence always ends.
+constexpr uint32_t RM_EMPTY = 0xFFFFFFFFu;
+__device__ inline uint64_t rm_mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+// what identifies a set member: the key and the bucket (two bits above any 64-bit key's hash input are not available: compare both)
+__device__ inline bool rm_same(const uint64_t* keys, const uint8_t* bkt_all, uint32_t o, uint64_t key, uint8_t b) { return keys[o] == key && bkt_all[o] == b; }
+__global__ void k_rm_insert(const uint64_t* keys, const uint8_t* bkt_all, uint64_t ord0, uint64_t npairs, uint32_t* table, uint64_t mask) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= npairs) return;
+    const uint32_t me = (uint32_t)(ord0 + r);
+    const uint8_t b = bkt_all[me];
+    if (b >= 4u) return;
+    const uint64_t key = keys[me];
+    uint64_t h = rm_mix(key + b) & mask;
+    for (;;) {
+        uint32_t cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == RM_EMPTY) {
+            cur = atomicCAS(&table[h], RM_EMPTY, me);
+            if (cur == RM_EMPTY) return;
+        }
+        if (rm_same(keys, bkt_all, cur, key, b)) { atomicMin(&table[h], me); return; }
+        h = (h + 1) & mask;
+    }
+}
+// state[pair of the segment]: 0 discarded, 1 duplicate, 2 + bucket kept
+__global__ void k_rm_mark(const uint64_t* keys, const uint8_t* bkt_all, uint64_t ord0, uint64_t npairs, const uint32_t* table, uint64_t mask, uint8_t* state,
+                          unsigned long long* counts /* uniq, dup, discard */) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t u = 0, d = 0, x = 0;
-    if (j < n) {
-        const SortRec r = rec[j];
-        if (r.lo >= 4u) { state[r.idx] = 0; x = 1; }
-        else if (j > 0 && rec[j - 1].lo == r.lo && rec[j - 1].hi == r.hi) { state[r.idx] = 1; d = 1; }
-        else { state[r.idx] = (uint8_t)(2u + r.lo); u = 1; }
+    if (r < npairs) {
+        const uint32_t me = (uint32_t)(ord0 + r);
+        const uint8_t b = bkt_all[me];
+        if (b >= 4u) { state[r] = 0; x = 1; }
+        else {
+            const uint64_t key = keys[me];
+            uint64_t h = rm_mix(key + b) & mask;
+            uint32_t cur;
+            for (;;) {
+                cur = table[h];
+                if (cur == RM_EMPTY || rm_same(keys, bkt_all, cur, key, b)) break;        // (EMPTY cannot happen: the pair was inserted)
+                h = (h + 1) & mask;
+            }
+            if (cur == me) { state[r] = (uint8_t)(2u + b); u = 1; } else { state[r] = 1; d = 1; }
+        }
     }
     const uint64_t bu = __ballot(u), bd = __ballot(d), bx = __ballot(x);
     if ((threadIdx.x & 63) == 0) {
         if (bu) atomicAdd(&counts[0], (unsigned long long)__popcll(bu));
         if (bd) atomicAdd(&counts[1], (unsigned long long)__popcll(bd));
         if (bx) atomicAdd(&counts[2], (unsigned long long)__popcll(bx));
+    }
+}
+// a bigger table: every ordinal of the old one goes in again (no two of them are the same set member)
+__global__ void k_rm_rehash(const uint32_t* old_table, uint64_t old_slots, const uint64_t* keys, const uint8_t* bkt_all, uint32_t* table, uint64_t mask) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= old_slots) return;
+    const uint32_t o = old_table[j];
+    if (o == RM_EMPTY) return;
+    uint64_t h = rm_mix(keys[o] + bkt_all[o]) & mask;
+    for (;;) {
+        if (table[h] == RM_EMPTY && atomicCAS(&table[h], RM_EMPTY, o) == RM_EMPTY) return;
+        h = (h + 1) & mask;
     }
 }
 // output order (krmdup.cpp:215-226): batch after batch of 2^16 input pairs; inside a batch bucket A's survivors, then C's, G's, T's,
@@ -744,9 +796,18 @@ __global__ __launch_bounds__(SWG) void k_rm_copy(const uint32_t* order, uint64_t
 struct mkt_rmdup {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint8_t* d_text = nullptr; size_t cap = 0, len = 0;
-    uint8_t* d_out[3] = {nullptr, nullptr, nullptr}; uint64_t out_len[3] = {0, 0, 0};
+    uint8_t* d_text = nullptr; size_t cap = 0, len = 0;      // the FASTQ bytes not worked on yet
+    uint8_t* d_out[3] = {nullptr, nullptr, nullptr}; uint64_t out_len[3] = {0, 0, 0}; size_t out_cap[3] = {0, 0, 0};
     bool done = false;
+    // the run (mkt_rmdup_begin .. the push with final != 0): the input goes through in SEGMENTS of whole 2^16-pair batches
+    bool begun = false;
+    mkt::RmParams P = {0, 0, 0, 0};
+    int interleaved = 0;
+    size_t seg_bytes = (size_t)256 << 20;                     // work off what is buffered once it is this much (MKT_RMDUP_SEGMENT_MB)
+    uint64_t pairs_done = 0;                                 // ordinal of the next pair
+    uint64_t stats[4] = {0, 0, 0, 0};
+    uint64_t* d_keys = nullptr; uint8_t* d_bkt = nullptr; size_t ord_cap = 0;      // key and bucket of every pair so far, by ordinal
+    uint32_t* d_table = nullptr; uint64_t slots = 0;         // the set: ordinals, open addressing, load <= 1/2
     std::string err;
 };
 static int rfail(mkt_rmdup* s, int code, const char* fmt, ...) {
@@ -760,35 +821,8 @@ static int rfail(mkt_rmdup* s, int code, const char* fmt, ...) {
 }
 #define RCHK(s, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return rfail((s), MKT_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 
-extern "C" {
-
-int mkt_rmdup_create(int device, mkt_rmdup** out) {
-    if (!out) return MKT_E_ARG;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MKT_E_NO_DEVICE;
-    if (device < 0 || device >= ndev) return MKT_E_ARG;
-    mkt_rmdup* s = new mkt_rmdup();
-    s->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return MKT_E_HIP; }
-    *out = s;
-    return MKT_OK;
-}
-void mkt_rmdup_destroy(mkt_rmdup* s) {
-    if (!s) return;
-    (void)hipSetDevice(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    if (s->d_text) (void)hipFree(s->d_text);
-    for (int k = 0; k < 3; ++k) if (s->d_out[k]) (void)hipFree(s->d_out[k]);
-    if (s->stream) (void)hipStreamDestroy(s->stream);
-    delete s;
-}
-const char* mkt_rmdup_error(const mkt_rmdup* s) { return s ? s->err.c_str() : ""; }
-
-// room for `need` bytes of FASTQ text.  The whole input is resident while it is worked on (the duplicate keys are global): growing
-// doubles the buffer -- old and new coexist during the copy -- and falls back to just enough when the doubled size does not fit;
-// what still does not fit is an input larger than one GPU takes (~40 % of the HBM for a pipe of unknown length,
-// ~45 % for a regular file, whose size is reserved once)
+// room for `need` bytes of FASTQ text that wait for their segment.  Growing doubles the buffer -- old and new coexist during the
+// copy -- and falls back to just enough when the doubled size does not fit.
 static int rmdup_room(mkt_rmdup* s, size_t need) {
     if (need <= s->cap) return MKT_OK;
     size_t ncap = s->cap ? s->cap : ((size_t)256 << 20);
@@ -800,47 +834,62 @@ static int rmdup_room(mkt_rmdup* s, size_t need) {
         (void)hipGetLastError();
         size_t fr = 0, tot = 0;
         (void)hipMemGetInfo(&fr, &tot);
-        return rfail(s, MKT_E_NOMEM, "the FASTQ input (%.1f GB so far) does not fit this GPU next to what is resident (%.1f of %.1f GB free): "
-                     "krmdup keeps the whole input in HBM; split the lanes (the driver's -b) or the file", (double)need / 1e9, (double)fr / 1e9, (double)tot / 1e9);
+        return rfail(s, MKT_E_NOMEM, "no room for %.1f GB of FASTQ text on this GPU (%.1f of %.1f GB free): with mkt_rmdup_push the input is worked off "
+                     "in segments; mkt_rmdup_add + mkt_rmdup_run keep all of it", (double)need / 1e9, (double)fr / 1e9, (double)tot / 1e9);
     }
     if (s->d_text) { if (s->len) RCHK(s, hipMemcpy(nb, s->d_text, s->len, hipMemcpyDeviceToDevice)); RCHK(s, hipFree(s->d_text)); }
     s->d_text = nb; s->cap = ncap;
     return MKT_OK;
 }
-int mkt_rmdup_reserve(mkt_rmdup* s, size_t bytes) {
-    if (!s) return MKT_E_ARG;
-    if (s->done) return rfail(s, MKT_E_STATE, "reserve after run");
-    RCHK(s, hipSetDevice(s->device));
-    return rmdup_room(s, bytes + 1);
-}
-int mkt_rmdup_add(mkt_rmdup* s, const char* bytes, size_t n) {
-    if (!s || (n && !bytes)) return MKT_E_ARG;
-    if (s->done) return rfail(s, MKT_E_STATE, "add after run");
-    RCHK(s, hipSetDevice(s->device));
-    { const int rc = rmdup_room(s, s->len + n + 1); if (rc) return rc; }
-    if (n) RCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes, n, hipMemcpyHostToDevice, s->stream));
-    RCHK(s, hipStreamSynchronize(s->stream));
-    s->len += n;
+// keys / buckets for ordinals < need; the table for that many members at load <= 1/2
+static int rmdup_set_room(mkt_rmdup* s, uint64_t need) {
+    hipStream_t st = s->stream;
+    if (need > s->ord_cap) {
+        size_t ncap = s->ord_cap ? s->ord_cap : ((size_t)1 << 17);      // (small: the growth paths run on every input of a few batches)
+        while (ncap < need) ncap *= 2;
+        uint64_t* nk = nullptr; uint8_t* nb = nullptr;
+        if (hipMalloc((void**)&nk, ncap * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&nb, ncap) != hipSuccess) {
+            (void)hipGetLastError();
+            if (nk) (void)hipFree(nk);
+            return rfail(s, MKT_E_NOMEM, "no room for the keys of %llu read pairs", (unsigned long long)need);
+        }
+        RCHK(s, hipStreamSynchronize(st));
+        if (s->pairs_done) { RCHK(s, hipMemcpy(nk, s->d_keys, s->pairs_done * sizeof(uint64_t), hipMemcpyDeviceToDevice)); RCHK(s, hipMemcpy(nb, s->d_bkt, s->pairs_done, hipMemcpyDeviceToDevice)); }
+        if (s->d_keys) RCHK(s, hipFree(s->d_keys));
+        if (s->d_bkt) RCHK(s, hipFree(s->d_bkt));
+        s->d_keys = nk; s->d_bkt = nb; s->ord_cap = ncap;
+    }
+    if (need * 2 > s->slots) {
+        uint64_t ns = s->slots ? s->slots : ((uint64_t)1 << 18);
+        while (ns < need * 2) ns *= 2;
+        uint32_t* nt = nullptr;
+        if (hipMalloc((void**)&nt, ns * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return rfail(s, MKT_E_NOMEM, "no room for a key set of %llu slots", (unsigned long long)ns); }
+        RCHK(s, hipMemsetAsync(nt, 0xFF, ns * sizeof(uint32_t), st));
+        if (s->d_table) {
+            hipLaunchKernelGGL(mkt::k_rm_rehash, dim3((unsigned)((s->slots + 255) / 256)), dim3(256), 0, st, (const uint32_t*)s->d_table, s->slots, (const uint64_t*)s->d_keys,
+                               (const uint8_t*)s->d_bkt, nt, ns - 1);
+            RCHK(s, hipGetLastError());
+            RCHK(s, hipStreamSynchronize(st));
+            RCHK(s, hipFree(s->d_table));
+        }
+        s->d_table = nt; s->slots = ns;
+    }
     return MKT_OK;
 }
 
-/* hskip / keylen as krmdup's -k -K -s -S (krmdup.cpp:229-262).  interleaved != 0: ONE output (read 1 and read 2 records alternating,
- * krmdup.pipe), else two.  stats: total, uniq, dup, discard (krmdup.cpp:377-390). */
-int mkt_rmdup_run(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved, uint64_t stats[4], uint64_t out_bytes[2]) {
-    if (!s || !stats || !out_bytes) return MKT_E_ARG;
-    if (keylen1 + keylen2 > 32 || keylen1 + keylen2 < 16) return rfail(s, MKT_E_ARG, "invalid key sizes (krmdup.cpp:258)");
-    RCHK(s, hipSetDevice(s->device));
-    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+// Work off what is buffered: every whole 2^16-pair batch (final: everything).  Outputs of the segment -> d_out[], sizes -> out_bytes.
+static int rmdup_segment(mkt_rmdup* s, bool final, uint64_t out_bytes[2]) {
+    using namespace mkt;
     out_bytes[0] = out_bytes[1] = 0;
-    s->done = true;
+    s->out_len[0] = s->out_len[1] = 0;
     if (s->len == 0) return MKT_OK;
-    {   // getline semantics: a missing final newline ends the last line all the same
+    hipStream_t st = s->stream;
+    if (final) {   // getline semantics: a missing final newline ends the last line all the same
         char last = 0;
         RCHK(s, hipMemcpy(&last, s->d_text + s->len - 1, 1, hipMemcpyDeviceToHost));
-        if (last != '\n') { const char nlc = '\n'; RCHK(s, hipMemcpy(s->d_text + s->len, &nlc, 1, hipMemcpyHostToDevice)); ++s->len; }
+        if (last != '\n') { { const int rc = rmdup_room(s, s->len + 2); if (rc) return rc; } const char nlc = '\n'; RCHK(s, hipMemcpy(s->d_text + s->len, &nlc, 1, hipMemcpyHostToDevice)); ++s->len; }
     }
     const uint64_t n = s->len;
-    hipStream_t st = s->stream;
     std::vector<void*> owned;
     auto cleanup = [&]() { for (void* p : owned) (void)hipFree(p); };
 #define RALLOC(ptr, bytes_) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes_)); if (e_ != hipSuccess) { cleanup(); return rfail(s, MKT_E_NOMEM, "hipMalloc of %zu bytes failed: %s", (size_t)(bytes_), hipGetErrorString(e_)); } owned.push_back((void*)(ptr)); } while (0)
@@ -853,54 +902,42 @@ int mkt_rmdup_run(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hski
     uint64_t nl = 0;
     RRUN(hipMemcpyAsync(&nl, d_cnt + chunks, sizeof nl, hipMemcpyDeviceToHost, st));
     RRUN(hipStreamSynchronize(st));
-    const uint64_t npairs = nl / 8;                          // a truncated last record is ignored (undefined in the reference)
-    if (npairs >= (1ull << 32)) { cleanup(); return rfail(s, MKT_E_ARG, "%llu pairs: indexed with 32 bits", (unsigned long long)npairs); }
-    if (npairs == 0) { cleanup(); return MKT_OK; }
+    const uint64_t avail = nl / 8;                           // (a truncated last record is ignored: undefined in the reference)
+    const uint64_t npairs = final ? avail : avail / RM_BATCH * RM_BATCH;
+    if (npairs == 0) { cleanup(); if (final) s->len = 0; return MKT_OK; }
+    if (s->pairs_done + npairs >= (1ull << 32) - 1) { cleanup(); return rfail(s, MKT_E_ARG, "%llu pairs: ordinals have 32 bits", (unsigned long long)(s->pairs_done + npairs)); }
+    { const int rc = rmdup_set_room(s, s->pairs_done + npairs); if (rc) { cleanup(); return rc; } }
     uint64_t* d_starts = nullptr;
-    SortRec *rA = nullptr, *rB = nullptr;
     uint8_t* d_state = nullptr;
-    uint32_t *d_hist = nullptr, *d_bcnt = nullptr, *d_order = nullptr;
+    uint32_t *d_bcnt = nullptr, *d_order = nullptr;
     unsigned long long* d_counts = nullptr;
     uint64_t* d_base = nullptr;
     const uint32_t nbatch = (uint32_t)((npairs + RM_BATCH - 1) / RM_BATCH);
     RALLOC(d_starts, (nl + 2) * sizeof(uint64_t));
-    RALLOC(rA, (npairs + 1) * sizeof(SortRec));
-    RALLOC(rB, (npairs + 1) * sizeof(SortRec));
     RALLOC(d_state, npairs + 64);
-    RALLOC(d_hist, (size_t)16 * 1024 * 4 + 256);
     RALLOC(d_bcnt, (size_t)nbatch * 4 * sizeof(uint32_t));
     RALLOC(d_base, (size_t)nbatch * 4 * sizeof(uint64_t));
     RALLOC(d_order, (npairs + 1) * sizeof(uint32_t));
     RALLOC(d_counts, 64);
     RRUN(hipMemsetAsync(d_counts, 0, 64, st));
     hipLaunchKernelGGL(k_nl_starts, dim3(chunks), dim3(SWG), 0, st, (const uint8_t*)s->d_text, n, (const uint64_t*)d_cnt, d_starts);
-    RmParams P;
-    P.hskip1 = hskip1; P.epos1 = hskip1 + keylen1; P.hskip2 = hskip2; P.epos2 = hskip2 + keylen2;
     const unsigned pgrid = (unsigned)((npairs + 255) / 256);
-    hipLaunchKernelGGL(k_rm_keys, dim3(pgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, npairs, P, rA);
-    uint32_t G = (uint32_t)((npairs + 8191) / 8192);
-    if (G > 1024) G = 1024;
-    if (G == 0) G = 1;
-    const uint64_t per = (npairs + G - 1) / G;
-    auto pass = [&](int which, int shift) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, npairs, per, which, shift, d_hist, G);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(SWG), 0, st, d_hist, 16u * G);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(G), dim3(SWG), 0, st, (const SortRec*)rA, npairs, per, which, shift, (const uint32_t*)d_hist, G, rB);
-        std::swap(rA, rB);
-    };
-    for (int sh = 0; sh < 64; sh += 4) pass(1, sh);          // the key ...
-    pass(0, 0);                                               // ... then the bucket (one set per bucket, krmdup.cpp:325)
-    hipLaunchKernelGGL(k_rm_mark, dim3(pgrid), dim3(256), 0, st, (const SortRec*)rA, npairs, d_state, d_counts);
+    const uint64_t ord0 = s->pairs_done, mask = s->slots - 1;
+    hipLaunchKernelGGL(k_rm_keys, dim3(pgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, npairs, s->P, ord0, s->d_keys, s->d_bkt);
+    hipLaunchKernelGGL(k_rm_insert, dim3(pgrid), dim3(256), 0, st, (const uint64_t*)s->d_keys, (const uint8_t*)s->d_bkt, ord0, npairs, s->d_table, mask);
+    hipLaunchKernelGGL(k_rm_mark, dim3(pgrid), dim3(256), 0, st, (const uint64_t*)s->d_keys, (const uint8_t*)s->d_bkt, ord0, npairs, (const uint32_t*)s->d_table, mask, d_state, d_counts);
     hipLaunchKernelGGL(k_rm_order, dim3(nbatch), dim3(SWG), 0, st, (const uint8_t*)d_state, npairs, (const uint64_t*)d_base, d_bcnt, d_order, 0);
     std::vector<uint32_t> bc((size_t)nbatch * 4);
     unsigned long long hc[3] = {0, 0, 0};
+    uint64_t text_end = 0;
     RRUN(hipMemcpyAsync(bc.data(), d_bcnt, bc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RRUN(hipMemcpyAsync(hc, d_counts, sizeof hc, hipMemcpyDeviceToHost, st));
+    RRUN(hipMemcpyAsync(&text_end, d_starts + 8 * npairs, sizeof text_end, hipMemcpyDeviceToHost, st));
     RRUN(hipStreamSynchronize(st));
     std::vector<uint64_t> base(bc.size());
     uint64_t nkept = 0;
     for (size_t k = 0; k < bc.size(); ++k) { base[k] = nkept; nkept += bc[k]; }
-    stats[1] = hc[0]; stats[2] = hc[1]; stats[3] = hc[2]; stats[0] = hc[0] + hc[1] + hc[2];
+    s->stats[1] += hc[0]; s->stats[2] += hc[1]; s->stats[3] += hc[2]; s->stats[0] += hc[0] + hc[1] + hc[2];
     if (nkept != hc[0]) { cleanup(); return rfail(s, MKT_E_KERNEL, "kept %llu pairs but counted %llu unique ones", (unsigned long long)nkept, hc[0]); }
     if (nkept) {
         RRUN(hipMemcpyAsync(d_base, base.data(), base.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -908,15 +945,20 @@ int mkt_rmdup_run(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hski
         const uint32_t wg = (uint32_t)((nkept + RPW - 1) / RPW);
         uint64_t* d_wsum = nullptr;
         RALLOC(d_wsum, ((size_t)wg + 2) * sizeof(uint64_t));
-        for (int which = interleaved ? 2 : 0; which < (interleaved ? 3 : 2); ++which) {
+        for (int which = s->interleaved ? 2 : 0; which < (s->interleaved ? 3 : 2); ++which) {
             hipLaunchKernelGGL(k_rm_sums, dim3(wg), dim3(SWG), 0, st, (const uint32_t*)d_order, nkept, (const uint64_t*)d_starts, which, d_wsum);
             RRUN(launch_exscan(d_wsum, wg, d_wsum + wg, st));
             uint64_t total = 0;
             RRUN(hipMemcpyAsync(&total, d_wsum + wg, sizeof total, hipMemcpyDeviceToHost, st));
             RRUN(hipStreamSynchronize(st));
-            const int slot = interleaved ? 0 : which;
-            if (s->d_out[slot]) { (void)hipFree(s->d_out[slot]); s->d_out[slot] = nullptr; }
-            { hipError_t e_ = hipMalloc((void**)&s->d_out[slot], total + 64); if (e_ != hipSuccess) { cleanup(); return rfail(s, MKT_E_NOMEM, "hipMalloc of the output failed: %s", hipGetErrorString(e_)); } }
+            const int slot = s->interleaved ? 0 : which;
+            if (s->out_cap[slot] < total + 64) {
+                if (s->d_out[slot]) { (void)hipFree(s->d_out[slot]); s->d_out[slot] = nullptr; s->out_cap[slot] = 0; }
+                const size_t want = (size_t)total + total / 8 + 64;
+                hipError_t e_ = hipMalloc((void**)&s->d_out[slot], want);
+                if (e_ != hipSuccess) { cleanup(); return rfail(s, MKT_E_NOMEM, "hipMalloc of the output failed: %s", hipGetErrorString(e_)); }
+                s->out_cap[slot] = want;
+            }
             hipLaunchKernelGGL(k_rm_copy, dim3(wg), dim3(SWG), 0, st, (const uint32_t*)d_order, nkept, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, which, (const uint64_t*)d_wsum, s->d_out[slot]);
             RRUN(hipGetLastError());
             RRUN(hipStreamSynchronize(st));
@@ -924,16 +966,119 @@ int mkt_rmdup_run(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hski
             out_bytes[slot] = total;
         }
     }
+    s->pairs_done += npairs;
+    // what is left (pairs of a batch that is not complete yet, a record that is not complete yet) moves to the front
+    const uint64_t rest = final ? 0 : n - text_end;
+    if (rest) {
+        if (rest <= text_end) RRUN(hipMemcpyAsync(s->d_text, s->d_text + text_end, rest, hipMemcpyDeviceToDevice, st));      // (no overlap)
+        else {
+            uint8_t* tmp = nullptr;
+            RALLOC(tmp, rest + 64);
+            RRUN(hipMemcpyAsync(tmp, s->d_text + text_end, rest, hipMemcpyDeviceToDevice, st));
+            RRUN(hipMemcpyAsync(s->d_text, tmp, rest, hipMemcpyDeviceToDevice, st));
+        }
+        RRUN(hipStreamSynchronize(st));
+    }
+    s->len = rest;
     cleanup();
 #undef RALLOC
 #undef RRUN
     return MKT_OK;
 }
 
+extern "C" {
+
+int mkt_rmdup_create(int device, mkt_rmdup** out) {
+    if (!out) return MKT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MKT_E_NO_DEVICE;
+    if (device < 0 || device >= ndev) return MKT_E_ARG;
+    mkt_rmdup* s = new mkt_rmdup();
+    s->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return MKT_E_HIP; }
+    { const char* e = getenv("MKT_RMDUP_SEGMENT_MB"); if (e && atol(e) > 0) s->seg_bytes = (size_t)atol(e) << 20; }
+    *out = s;
+    return MKT_OK;
+}
+void mkt_rmdup_destroy(mkt_rmdup* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->d_text) (void)hipFree(s->d_text);
+    if (s->d_keys) (void)hipFree(s->d_keys);
+    if (s->d_bkt) (void)hipFree(s->d_bkt);
+    if (s->d_table) (void)hipFree(s->d_table);
+    for (int k = 0; k < 3; ++k) if (s->d_out[k]) (void)hipFree(s->d_out[k]);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+const char* mkt_rmdup_error(const mkt_rmdup* s) { return s ? s->err.c_str() : ""; }
+
+int mkt_rmdup_reserve(mkt_rmdup* s, size_t bytes) {
+    if (!s) return MKT_E_ARG;
+    if (s->done) return rfail(s, MKT_E_STATE, "reserve after the end of the run");
+    RCHK(s, hipSetDevice(s->device));
+    return rmdup_room(s, bytes + 1);
+}
+int mkt_rmdup_add(mkt_rmdup* s, const char* bytes, size_t n) {
+    if (!s || (n && !bytes)) return MKT_E_ARG;
+    if (s->done) return rfail(s, MKT_E_STATE, "add after the end of the run");
+    RCHK(s, hipSetDevice(s->device));
+    { const int rc = rmdup_room(s, s->len + n + 2); if (rc) return rc; }
+    if (n) RCHK(s, hipMemcpyAsync(s->d_text + s->len, bytes, n, hipMemcpyHostToDevice, s->stream));
+    RCHK(s, hipStreamSynchronize(s->stream));
+    s->len += n;
+    return MKT_OK;
+}
+
+/* hskip / keylen as krmdup's -k -K -s -S (krmdup.cpp:229-262).  interleaved != 0: ONE output (read 1 and read 2 records alternating,
+ * krmdup.pipe), else two. */
+int mkt_rmdup_begin(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved) {
+    if (!s) return MKT_E_ARG;
+    if (s->begun || s->done) return rfail(s, MKT_E_STATE, "one run per object");
+    if (keylen1 + keylen2 > 32 || keylen1 + keylen2 < 16) return rfail(s, MKT_E_ARG, "invalid key sizes (krmdup.cpp:258)");
+    s->P.hskip1 = hskip1; s->P.epos1 = hskip1 + keylen1; s->P.hskip2 = hskip2; s->P.epos2 = hskip2 + keylen2;
+    s->interleaved = interleaved ? 1 : 0;
+    s->begun = true;
+    return MKT_OK;
+}
+/* the next bytes of the stream (may be none).  Whenever a segment's worth is buffered -- and at the end, final != 0 -- the whole
+ * 2^16-pair batches in the buffer are worked off: out_bytes = what that left in the outputs (fetch it before the next push), else 0, 0 */
+int mkt_rmdup_push(mkt_rmdup* s, const char* bytes, size_t n, int final, uint64_t out_bytes[2]) {
+    if (!s || !out_bytes || (n && !bytes)) return MKT_E_ARG;
+    out_bytes[0] = out_bytes[1] = 0;
+    if (!s->begun) return rfail(s, MKT_E_STATE, "push before begin");
+    if (s->done) return rfail(s, MKT_E_STATE, "push after the end of the run");
+    if (n) { const int rc = mkt_rmdup_add(s, bytes, n); if (rc) return rc; }
+    RCHK(s, hipSetDevice(s->device));
+    if (!final && s->len < s->seg_bytes) { s->out_len[0] = s->out_len[1] = 0; return MKT_OK; }
+    const int rc = rmdup_segment(s, final != 0, out_bytes);
+    if (final && rc == MKT_OK) s->done = true;
+    return rc;
+}
+/* total, uniq, dup, discard so far (krmdup.cpp:377-390) */
+int mkt_rmdup_stats(const mkt_rmdup* s, uint64_t stats[4]) {
+    if (!s || !stats) return MKT_E_ARG;
+    for (int k = 0; k < 4; ++k) stats[k] = s->stats[k];
+    return MKT_OK;
+}
+/* everything added so far as ONE segment (the whole input resident: for inputs that fit; the streaming form is begin / push) */
+int mkt_rmdup_run(mkt_rmdup* s, uint32_t hskip1, uint32_t keylen1, uint32_t hskip2, uint32_t keylen2, int interleaved, uint64_t stats[4], uint64_t out_bytes[2]) {
+    if (!s || !stats || !out_bytes) return MKT_E_ARG;
+    int rc = mkt_rmdup_begin(s, hskip1, keylen1, hskip2, keylen2, interleaved);
+    if (rc) return rc;
+    RCHK(s, hipSetDevice(s->device));
+    rc = rmdup_segment(s, true, out_bytes);
+    s->done = true;
+    for (int k = 0; k < 4; ++k) stats[k] = s->stats[k];
+    return rc;
+}
+
 /* output `which` (0: read 1 or the interleaved stream, 1: read 2), bytes [off, off + n) */
 int mkt_rmdup_fetch(mkt_rmdup* s, int which, uint64_t off, char* out, size_t n) {
     if (!s || which < 0 || which > 1 || (n && !out)) return MKT_E_ARG;
-    if (!s->done) return rfail(s, MKT_E_STATE, "fetch before run");
+    if (!s->begun) return rfail(s, MKT_E_STATE, "fetch before run");
     if (off + n > s->out_len[which]) return rfail(s, MKT_E_ARG, "range past the end of the output");
     RCHK(s, hipSetDevice(s->device));
     if (n) RCHK(s, hipMemcpy(out, s->d_out[which] + off, n, hipMemcpyDeviceToHost));

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 20
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mkt.h but not exported"
-    assert lib.mkt_abi_version() == 8
+    assert lib.mkt_abi_version() == 9
     # and the Python binding lists the same entry points
     from microcket_amd import capi
     assert set(capi.EXPORTS) == set(names)

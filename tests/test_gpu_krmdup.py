@@ -38,6 +38,35 @@ def test_rmdup_edge_inputs_vs_oracle():
         assert (r1, r2, util.krmdup_log(*st)) == (o1, o2, ol), len(text)
 
 
+def test_rmdup_streaming_segments_equal_the_oracle(monkeypatch):
+    """begin / push / push(final) with segments far smaller than the input (MKT_RMDUP_SEGMENT_MB=8: a few 2^16-pair batches each, the
+    key set carried from segment to segment, growing and rehashing on the way) == the oracle == one resident run; pieces that cut
+    lines and records anywhere; duplicates whose first occurrence lies segments back; an all-G key (every bit set) and the same bases
+    in lower case (same key, other bucket: both stay, krmdup.cpp:105-108 / 171-176)."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    monkeypatch.setenv("MKT_RMDUP_SEGMENT_MB", "8")
+    g = "G" * 40
+    odd = (f"@g1 1\n{g}\n+\n{'F' * 40}\n@g1 2\n{g}\n+\n{'F' * 40}\n"
+           f"@g2 1\n{g.lower()}\n+\n{'F' * 40}\n@g2 2\n{g}\n+\n{'F' * 40}\n").encode()
+    a = util.synth_fastq(71, 150000, 36, dup_rate=0.4)
+    b = util.synth_fastq(72, 120000, 36, dup_rate=0.2)
+    la = a.split(b"\n")
+    half = b"\n".join(la[:len(la) // 16 * 8]) + b"\n"    # (whole pairs)
+    text = odd + a + b + half + odd                      # the fourth part repeats pairs seen 270 000 pairs earlier
+    assert text.count(b"\n") // 8 > 4 * 65536
+    o1, o2, ol = util.krmdup_oracle(text)
+    for piece in (1 << 22, 999983):
+        r1, r2, st = m.rmdup(text, piece=piece, stream=True)
+        assert util.krmdup_log(*st) == ol
+        assert (util.sha(r1), util.sha(r2)) == (util.sha(o1), util.sha(o2)), piece
+    q1, q2, st2 = m.rmdup(text)                           # resident form: one segment
+    assert (q1, q2, util.krmdup_log(*st2)) == (o1, o2, ol)
+    inter, _none, st3 = m.rmdup(text, interleaved=True, piece=1 << 22, stream=True)
+    l1, l2 = o1.split(b"\n")[:-1], o2.split(b"\n")[:-1]
+    assert st3 == st2 and inter == b"".join(b"\n".join(l1[i:i + 4] + l2[i:i + 4]) + b"\n" for i in range(0, len(l1), 4))
+
+
 def test_krmdup_executables_are_drop_ins():
     if m.device_count() < 1:
         pytest.fail("no HIP device")
