@@ -443,14 +443,33 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
 // per-lane bounds.  Otherwise groups and lanes past the window read its last group / vector again -- no branch, no exec mask,
 // no zero fill in front of the loads (a conditional load costs a wait right behind it) -- and what they read is ignored.
 constexpr int kLoadBatch = 14;
-__device__ inline uint64_t has_newline_ballot(const uint4& y, bool valid) {
-    const uint32_t t0 = y.x ^ 0x0A0A0A0Au, t1 = y.y ^ 0x0A0A0A0Au, t2 = y.z ^ 0x0A0A0A0Au, t3 = y.w ^ 0x0A0A0A0Au;
-    const uint32_t z = ((t0 - 0x01010101u) & ~t0) | ((t1 - 0x01010101u) & ~t1) | ((t2 - 0x01010101u) & ~t2) | ((t3 - 0x01010101u) & ~t3);
-    return __ballot((z & 0x80808080u) != 0u && valid);
+// "some byte of y is a newline": with t = y ^ 0x0A0A0A0A, (t - 0x01010101) & ~t & 0x80808080 != 0.  Eleven VALU instructions per
+// 16-byte vector: per dword ONE v_xad_u32 ((y ^ nl) + (-0x01010101); the compiler splits it into xor + add) and ONE three-input
+// v_bitop3 (z & ~(y ^ nl): truth table 0xF0 & ~(0xCC ^ 0xAA) = 0x90), then the four dwords ORed and masked by two more, one compare.
+__device__ inline uint32_t nl_xad(uint32_t y, uint32_t nl, uint32_t m1) {
+    uint32_t r;
+    asm("v_xad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(y), "s"(nl), "v"(m1));
+    return r;
+}
+struct NlConst { uint32_t nl, m1; };                     // 0x0A0A0A0A in a scalar, -0x01010101 in a vector register: one instruction cannot take two literals
+__device__ inline NlConst nl_const() {
+    NlConst c;
+    c.nl = 0x0A0A0A0Au; c.m1 = 0xFEFEFEFFu;
+    asm volatile("" : "+s"(c.nl));
+    asm volatile("" : "+v"(c.m1));
+    return c;
+}
+__device__ inline uint64_t has_newline_ballot(const uint4& y, bool valid, const NlConst& c) {
+    const uint32_t nl = c.nl, m1 = c.m1;
+    const uint32_t r0 = __builtin_amdgcn_bitop3_b32(nl_xad(y.x, nl, m1), y.x, nl, 0x90), r1 = __builtin_amdgcn_bitop3_b32(nl_xad(y.y, nl, m1), y.y, nl, 0x90);
+    const uint32_t r2 = __builtin_amdgcn_bitop3_b32(nl_xad(y.z, nl, m1), y.z, nl, 0x90), r3 = __builtin_amdgcn_bitop3_b32(nl_xad(y.w, nl, m1), y.w, nl, 0x90);
+    const uint32_t z = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(r0, r1, r2, 0xFE), r3, 0x80808080u, 0xA8);      // (a | b | c), then (a | b) & c
+    return __ballot(z != 0u && valid);
 }
 template <class Cfg, uint32_t nws>
 __device__ inline void fast_scan(const KArgs& a, uint32_t tt, uint64_t* hit, uint32_t ws_, uint32_t kb, uint32_t ke, int lane) {
     const uint32_t ws = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws_);      // (wave-uniform: the group arithmetic below is scalar)
+    const NlConst nlc = nl_const();
     const uint32_t n = a.n;
     const TileGeom G = tile_geom(tt, n, a.dims);
     const uint32_t wlen = G.w1 - G.w0, nvec = (wlen + 15u) >> 4;
@@ -469,7 +488,7 @@ __device__ inline void fast_scan(const KArgs& a, uint32_t tt, uint64_t* hit, uin
 #pragma unroll
         for (int k = 0; k < kLoadBatch; ++k) {
             if ((uint32_t)k < cnt) {                   // (no break: the array must stay in registers, every index a constant)
-                const uint64_t bm = has_newline_ballot(x[k], true);
+                const uint64_t bm = has_newline_ballot(x[k], true, nlc);
                 const uint32_t g = (kb + (uint32_t)k) * nws + ws;
                 if (lane == 0 && g < (uint32_t)Cfg::HMW) hit[g] = bm;
             }
@@ -499,7 +518,7 @@ __device__ inline void fast_scan(const KArgs& a, uint32_t tt, uint64_t* hit, uin
                     w[d] = tail >= lo + 4u ? w[d] : (tail > lo ? (w[d] & ((1u << ((tail - lo) * 8u)) - 1u)) : 0u);
                 }
             }
-            const uint64_t bm = has_newline_ballot(y, (uint32_t)lane < nvec - (g << 6));
+            const uint64_t bm = has_newline_ballot(y, (uint32_t)lane < nvec - (g << 6), nlc);
             if (lane == 0 && g < (uint32_t)Cfg::HMW) hit[g] = bm;
         }
     }
