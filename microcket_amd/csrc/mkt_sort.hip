@@ -658,7 +658,8 @@ constexpr uint32_t RM_EMPTY = 0xFFFFFFFFu;
 __device__ inline uint64_t rm_mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
 // what identifies a set member: the key and the bucket (two bits above any 64-bit key's hash input are not available: compare both)
 __device__ inline bool rm_same(const uint64_t* keys, const uint8_t* bkt_all, uint32_t o, uint64_t key, uint8_t b) { return keys[o] == key && bkt_all[o] == b; }
-__global__ void k_rm_insert(const uint64_t* keys, const uint8_t* bkt_all, uint64_t ord0, uint64_t npairs, uint32_t* table, uint64_t mask) {
+constexpr uint32_t RM_MAX_PROBES = 1u << 22;                  // (a probe sequence that long means the table is not what the host thinks: an error, never a hang)
+__global__ void k_rm_insert(const uint64_t* keys, const uint8_t* bkt_all, uint64_t ord0, uint64_t npairs, uint32_t* table, uint64_t mask, unsigned long long* err) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= npairs) return;
     const uint32_t me = (uint32_t)(ord0 + r);
@@ -666,7 +667,7 @@ __global__ void k_rm_insert(const uint64_t* keys, const uint8_t* bkt_all, uint64
     if (b >= 4u) return;
     const uint64_t key = keys[me];
     uint64_t h = rm_mix(key + b) & mask;
-    for (;;) {
+    for (uint32_t step = 0; step < RM_MAX_PROBES; ++step) {
         uint32_t cur = __hip_atomic_load(&table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == RM_EMPTY) {
             cur = atomicCAS(&table[h], RM_EMPTY, me);
@@ -675,6 +676,7 @@ __global__ void k_rm_insert(const uint64_t* keys, const uint8_t* bkt_all, uint64
         if (rm_same(keys, bkt_all, cur, key, b)) { atomicMin(&table[h], me); return; }
         h = (h + 1) & mask;
     }
+    atomicAdd(err, 1ull);
 }
 // state[pair of the segment]: 0 discarded, 1 duplicate, 2 + bucket kept
 __global__ void k_rm_mark(const uint64_t* keys, const uint8_t* bkt_all, uint64_t ord0, uint64_t npairs, const uint32_t* table, uint64_t mask, uint8_t* state,
@@ -688,12 +690,14 @@ __global__ void k_rm_mark(const uint64_t* keys, const uint8_t* bkt_all, uint64_t
         else {
             const uint64_t key = keys[me];
             uint64_t h = rm_mix(key + b) & mask;
-            uint32_t cur;
-            for (;;) {
+            uint32_t cur = RM_EMPTY;
+            for (uint32_t step = 0; step < RM_MAX_PROBES; ++step) {
                 cur = table[h];
                 if (cur == RM_EMPTY || rm_same(keys, bkt_all, cur, key, b)) break;        // (EMPTY cannot happen: the pair was inserted)
                 h = (h + 1) & mask;
+                cur = RM_EMPTY;
             }
+            if (cur == RM_EMPTY) atomicAdd(&counts[3], 1ull);                               // (reported as an error by the host)
             if (cur == me) { state[r] = (uint8_t)(2u + b); u = 1; } else { state[r] = 1; d = 1; }
         }
     }
@@ -705,16 +709,17 @@ __global__ void k_rm_mark(const uint64_t* keys, const uint8_t* bkt_all, uint64_t
     }
 }
 // a bigger table: every ordinal of the old one goes in again (no two of them are the same set member)
-__global__ void k_rm_rehash(const uint32_t* old_table, uint64_t old_slots, const uint64_t* keys, const uint8_t* bkt_all, uint32_t* table, uint64_t mask) {
+__global__ void k_rm_rehash(const uint32_t* old_table, uint64_t old_slots, const uint64_t* keys, const uint8_t* bkt_all, uint32_t* table, uint64_t mask, unsigned long long* err) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= old_slots) return;
     const uint32_t o = old_table[j];
     if (o == RM_EMPTY) return;
     uint64_t h = rm_mix(keys[o] + bkt_all[o]) & mask;
-    for (;;) {
+    for (uint32_t step = 0; step < RM_MAX_PROBES; ++step) {
         if (table[h] == RM_EMPTY && atomicCAS(&table[h], RM_EMPTY, o) == RM_EMPTY) return;
         h = (h + 1) & mask;
     }
+    atomicAdd(err, 1ull);
 }
 // output order (krmdup.cpp:215-226): batch after batch of 2^16 input pairs; inside a batch bucket A's survivors, then C's, G's, T's,
 // each in input order.  One workgroup per batch: kept pairs per bucket (pass 0), then their slots (pass 1, base[] from the host scan).
@@ -808,6 +813,7 @@ struct mkt_rmdup {
     uint64_t stats[4] = {0, 0, 0, 0};
     uint64_t* d_keys = nullptr; uint8_t* d_bkt = nullptr; size_t ord_cap = 0;      // key and bucket of every pair so far, by ordinal
     uint32_t* d_table = nullptr; uint64_t slots = 0;         // the set: ordinals, open addressing, load <= 1/2
+    unsigned long long* d_err = nullptr;                     // probe sequences that did not end (none, ever: checked after every segment)
     std::string err;
 };
 static int rfail(mkt_rmdup* s, int code, const char* fmt, ...) {
@@ -867,7 +873,7 @@ static int rmdup_set_room(mkt_rmdup* s, uint64_t need) {
         RCHK(s, hipMemsetAsync(nt, 0xFF, ns * sizeof(uint32_t), st));
         if (s->d_table) {
             hipLaunchKernelGGL(mkt::k_rm_rehash, dim3((unsigned)((s->slots + 255) / 256)), dim3(256), 0, st, (const uint32_t*)s->d_table, s->slots, (const uint64_t*)s->d_keys,
-                               (const uint8_t*)s->d_bkt, nt, ns - 1);
+                               (const uint8_t*)s->d_bkt, nt, ns - 1, s->d_err);
             RCHK(s, hipGetLastError());
             RCHK(s, hipStreamSynchronize(st));
             RCHK(s, hipFree(s->d_table));
@@ -924,16 +930,18 @@ static int rmdup_segment(mkt_rmdup* s, bool final, uint64_t out_bytes[2]) {
     const unsigned pgrid = (unsigned)((npairs + 255) / 256);
     const uint64_t ord0 = s->pairs_done, mask = s->slots - 1;
     hipLaunchKernelGGL(k_rm_keys, dim3(pgrid), dim3(256), 0, st, (const uint8_t*)s->d_text, (const uint64_t*)d_starts, npairs, s->P, ord0, s->d_keys, s->d_bkt);
-    hipLaunchKernelGGL(k_rm_insert, dim3(pgrid), dim3(256), 0, st, (const uint64_t*)s->d_keys, (const uint8_t*)s->d_bkt, ord0, npairs, s->d_table, mask);
+    hipLaunchKernelGGL(k_rm_insert, dim3(pgrid), dim3(256), 0, st, (const uint64_t*)s->d_keys, (const uint8_t*)s->d_bkt, ord0, npairs, s->d_table, mask, s->d_err);
     hipLaunchKernelGGL(k_rm_mark, dim3(pgrid), dim3(256), 0, st, (const uint64_t*)s->d_keys, (const uint8_t*)s->d_bkt, ord0, npairs, (const uint32_t*)s->d_table, mask, d_state, d_counts);
     hipLaunchKernelGGL(k_rm_order, dim3(nbatch), dim3(SWG), 0, st, (const uint8_t*)d_state, npairs, (const uint64_t*)d_base, d_bcnt, d_order, 0);
     std::vector<uint32_t> bc((size_t)nbatch * 4);
-    unsigned long long hc[3] = {0, 0, 0};
+    unsigned long long hc[4] = {0, 0, 0, 0}, herr = 0;
     uint64_t text_end = 0;
     RRUN(hipMemcpyAsync(bc.data(), d_bcnt, bc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     RRUN(hipMemcpyAsync(hc, d_counts, sizeof hc, hipMemcpyDeviceToHost, st));
     RRUN(hipMemcpyAsync(&text_end, d_starts + 8 * npairs, sizeof text_end, hipMemcpyDeviceToHost, st));
+    RRUN(hipMemcpyAsync(&herr, s->d_err, sizeof herr, hipMemcpyDeviceToHost, st));
     RRUN(hipStreamSynchronize(st));
+    if (herr | hc[3]) { cleanup(); return rfail(s, MKT_E_KERNEL, "the key set's probe sequences did not end (%llu inserts, %llu lookups)", herr, hc[3]); }
     std::vector<uint64_t> base(bc.size());
     uint64_t nkept = 0;
     for (size_t k = 0; k < bc.size(); ++k) { base[k] = nkept; nkept += bc[k]; }
@@ -998,6 +1006,9 @@ int mkt_rmdup_create(int device, mkt_rmdup** out) {
     s->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { delete s; return MKT_E_HIP; }
     { const char* e = getenv("MKT_RMDUP_SEGMENT_MB"); if (e && atol(e) > 0) s->seg_bytes = (size_t)atol(e) << 20; }
+    if (hipMalloc((void**)&s->d_err, sizeof(unsigned long long)) != hipSuccess || hipMemset(s->d_err, 0, sizeof(unsigned long long)) != hipSuccess) {
+        (void)hipStreamDestroy(s->stream); delete s; return MKT_E_HIP;
+    }
     *out = s;
     return MKT_OK;
 }
@@ -1009,6 +1020,7 @@ void mkt_rmdup_destroy(mkt_rmdup* s) {
     if (s->d_keys) (void)hipFree(s->d_keys);
     if (s->d_bkt) (void)hipFree(s->d_bkt);
     if (s->d_table) (void)hipFree(s->d_table);
+    if (s->d_err) (void)hipFree(s->d_err);
     for (int k = 0; k < 3; ++k) if (s->d_out[k]) (void)hipFree(s->d_out[k]);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
