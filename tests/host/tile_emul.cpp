@@ -281,4 +281,9 @@ int emul_run(const char* text, size_t n, int mode, float ratio, int min_mapq, in
     return 0;
 }
 void emul_free(void* p) { free(p); }
+// the run-time tile geometry for an average line length (mkt_fast.h: lean_dims) and the capacities it must stay inside
+void emul_lean_dims(double avg_line_bytes, uint32_t* out /* tile, hb, hf, max tile, max hb, max hf */) {
+    const TileDims d = lean_dims(avg_line_bytes);
+    out[0] = d.tile; out[1] = d.hb; out[2] = d.hf; out[3] = (uint32_t)kLeanTile; out[4] = (uint32_t)kLeanHB; out[5] = (uint32_t)kLeanHF;
+}
 }
