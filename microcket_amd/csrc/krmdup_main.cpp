@@ -89,9 +89,20 @@ int main(int argc, char* argv[]) {
         }
         return true;
     };
+    // a regular file is read in 64 MiB pieces; a pipe in pieces of at most 4 MiB of what has arrived (read(2), not fread: waiting for a
+    // full buffer would hold back reads the consumer behind us could already have)
+    const int ifd = fileno(fin);
+    size_t piece = (size_t)4 << 20;
+    { struct stat sb; if (fstat(ifd, &sb) == 0 && S_ISREG(sb.st_mode)) piece = buf.size(); }
     size_t k;
     for (;;) {
-        k = fread(buf.data(), 1, buf.size(), fin);
+        k = 0;
+        while (k < piece) {
+            const ssize_t g = read(ifd, buf.data() + k, piece - k);
+            if (g < 0) { if (errno == EINTR) continue; std::cerr << "Error: read fastq failed!\n"; return 10; }
+            if (g == 0) break;
+            k += (size_t)g;
+        }
         rc = mkt_rmdup_push(r, buf.data(), k, k == 0 ? 1 : 0, ob);
         if (rc != MKT_OK) { std::cerr << "Error: " << mkt_strerror(rc) << ": " << mkt_rmdup_error(r) << "\n"; return 21; }
         if ((ob[0] | ob[1]) && !drain()) { std::cerr << "Error: write output failed!\n"; return 22; }

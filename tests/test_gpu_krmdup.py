@@ -88,3 +88,51 @@ def test_krmdup_executables_are_drop_ins():
     import subprocess
     assert subprocess.run([exe], stderr=subprocess.PIPE).returncode == 2
     assert subprocess.run([exe, "-i", "x", "-o", "y", "-s", "3", "-S", "3"], stderr=subprocess.PIPE).returncode == 1
+
+
+def test_krmdup_pipe_streams_in_the_drivers_pipe():
+    """microcket:405-408: `ktrim ... | krmdup.pipe -i /dev/stdin -o prefix | flash ...`.  The executable reads a pipe that delivers the
+    FASTQ in small writes, works it off in segments (MKT_RMDUP_SEGMENT_MB=8) and -- the point of streaming -- its first reads leave
+    while input is still arriving: the reader below waits for output before it sends the second half."""
+    if m.device_count() < 1:
+        pytest.fail("no HIP device")
+    import subprocess
+    import tempfile
+    import threading
+    exe = os.path.join(os.path.dirname(m.exe_path()), "krmdup.pipe")
+    text = util.synth_fastq(91, 300000, 36, dup_rate=0.3)
+    o1, o2, ol = util.krmdup_oracle(text)
+    l1, l2 = o1.split(b"\n")[:-1], o2.split(b"\n")[:-1]
+    want = b"".join(b"\n".join(l1[i:i + 4] + l2[i:i + 4]) + b"\n" for i in range(0, len(l1), 4))
+    with tempfile.TemporaryDirectory(prefix="krmp_") as d:
+        pre = os.path.join(d, "o")
+        p = subprocess.Popen([exe, "-i", "/dev/stdin", "-o", pre], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             env=dict(os.environ, MKT_RMDUP_SEGMENT_MB="8"))
+        got = []
+        first_out = threading.Event()
+
+        def reader():
+            while True:
+                b = p.stdout.read(1 << 20)
+                if not b:
+                    break
+                got.append(b)
+                first_out.set()
+
+        th = threading.Thread(target=reader)
+        th.start()
+        half = len(text) // 2
+        for k in range(0, half, 1 << 16):
+            p.stdin.write(text[k:min(k + (1 << 16), half)])
+        p.stdin.flush()
+        early = first_out.wait(60)                       # output of the first segments before the input is complete
+        for k in range(half, len(text), 1 << 16):
+            p.stdin.write(text[k:k + (1 << 16)])
+        p.stdin.close()
+        th.join()
+        rc = p.wait()
+        err = p.stderr.read()
+        assert rc == 0, err
+        assert early, "no read left the executable before its input ended"
+        assert b"".join(got) == want
+        assert open(pre + ".log", "rb").read() == ol
