@@ -106,6 +106,7 @@ struct mkt_ctx {
     uint64_t* d_syn_sizes = nullptr; size_t syn_sizes_cap = 0;
     unsigned long long* d_stamps = nullptr;   // diagnostic builds (MKT_STAMPS) only
     bool no_lean = false;                     // MKT_NO_LEAN=1: generic kernel only (debugging aid)
+    int halo_widened = 0;                     // times adapt_geometry widened the halos of this input (at most twice)
     std::string err;
 };
 
@@ -282,6 +283,7 @@ static int ensure_sc_list(mkt_ctx* c, size_t need);
 // the way), the following blocks use tiles of 0.6 x the bytes.
 static void set_dims_from_avg(mkt_ctx* c, double bytes_per_line) {
     c->dims_probed = true;
+    c->halo_widened = 0;
     if (c->cfg == CFG_SMALL || c->p.tiles != MKT_TILES_AUTO) return;
     c->dims = lean_dims(bytes_per_line);
     if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "tile geometry: %.1f bytes per line -> tile %u, halos %u / %u\n", bytes_per_line, c->dims.tile, c->dims.hb, c->dims.hf);
@@ -292,8 +294,24 @@ static bool shrink_dims(mkt_ctx* c) {
     c->dims.tile = f(c->dims.tile, 2048u); c->dims.hb = f(c->dims.hb, 256u); c->dims.hf = f(c->dims.hf, 512u);
     return true;
 }
+// halos half as wide again, the window as it was (the tile gives the bytes): for an input whose groups reach further than the
+// default halos (many lines per read name), seen as tiles left to the generic kernel
+static bool widen_halos(mkt_ctx* c) {
+    if (c->cfg == CFG_SMALL || c->halo_widened >= 2) return false;
+    const TileDims mx = max_dims();
+    auto f = [](uint32_t x, uint32_t hi) { uint32_t y = ((uint32_t)(x * 1.5) + 15u) & ~15u; return y > hi ? hi : y; };
+    const uint32_t hb = f(c->dims.hb, mx.hb), hf = f(c->dims.hf, mx.hf);
+    const uint32_t delta = (hb - c->dims.hb) + (hf - c->dims.hf);
+    if (delta == 0 || c->dims.tile < delta + 2048u) return false;
+    c->dims.tile -= delta; c->dims.hb = hb; c->dims.hf = hf;
+    ++c->halo_widened;
+    if (getenv("MKT_DEBUG_SYNC")) fprintf(stderr, "tile geometry: halos widened -> tile %u, halos %u / %u\n", c->dims.tile, c->dims.hb, c->dims.hf);
+    return true;
+}
 static bool adapt_geometry(mkt_ctx* c, const BlockResult& r) {
-    if (c->p.tiles == MKT_TILES_AUTO && !c->p.ordered && r.tiles >= 8 && (uint64_t)r.pad * 8 > r.tiles) return shrink_dims(c);
+    if (c->p.tiles != MKT_TILES_AUTO || c->p.ordered) return false;
+    if (r.tiles >= 1000 && (uint64_t)r.pad2 * 500 > r.tiles && widen_halos(c)) return true;      // more than 0.2 % of the tiles deferred for their halos
+    if (r.tiles >= 8 && (uint64_t)(r.pad - r.pad2) * 8 > r.tiles) return shrink_dims(c);
     return false;
 }
 // bytes per line of device-resident text (its first MiB); the context's stream is idle afterwards.  0: could not tell

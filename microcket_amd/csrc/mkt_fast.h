@@ -40,12 +40,17 @@ constexpr int kLeanLinesTarget = 126;      // lines per window the host aims at:
 // the kernel's capacities.  Halos are sized by what a deferred tile costs: a pass of the generic kernel takes 0.1 - 0.2 ms for a
 // handful of tiles, a tenth of a block's time.  Measured on the bench data: back 5 / forward 7.5 lines: one tile in 21 000
 // deferred (two per 2 GB block); 7.5 / 7.5: one in 170 000 (all "group open at the end of the window").
+// halos in lines: the previous surviving line is almost always one of the six lines in front of the tile, a group that starts in the
+// tile almost always ends within seven lines behind it (one tile in ~10^5 of the bench's data is left to the generic kernel for its
+// halo; 7.5 / 8.75 lines: none, 4 / 5 lines: one in 10^3 -- profiles/r03_raw/halo_sweep.txt).  An input whose groups are longer makes
+// the host widen them (mkt_capi.cpp: adapt_geometry)
+constexpr double kLeanHaloBackLines = 6.0, kLeanHaloFwdLines = 7.0;
 MKT_HD TileDims lean_dims(double avg) {
     if (avg < 48.0) avg = 48.0;
     if (avg > 4096.0) avg = 4096.0;
     auto r16 = [](double x) { return ((uint32_t)x + 15u) & ~15u; };
     TileDims d;
-    d.hb = r16(7.5 * avg); d.hf = r16(8.75 * avg);
+    d.hb = r16(kLeanHaloBackLines * avg); d.hf = r16(kLeanHaloFwdLines * avg);
     if (d.hb < 256u) d.hb = 256u;
     if (d.hb > (uint32_t)kLeanHB) d.hb = (uint32_t)kLeanHB;
     if (d.hf < 512u) d.hf = 512u;

@@ -23,7 +23,7 @@ struct BlockResult {            // written by the device (finish kernel), POD
     uint32_t err;
     TileLast last;              // last group of the block (valid = 0: the block holds no group)
     uint32_t tiles, pad;
-    uint32_t nregions, pad2;    // outputs sit in nregions equal slices of the output buffers (any-order mode: 16)
+    uint32_t nregions, pad2;    // outputs sit in nregions equal slices of the output buffers (any-order mode: 16); pad2: deferred tiles a wider halo would have kept
     uint64_t rpair[16], rsam[16];   // bytes used in each slice
 };
 

@@ -770,7 +770,12 @@ __global__ __launch_bounds__(NTW, WPS) void k_fast(KArgs a) {
         STAMP(6);
         STOP_AFTER(6)
         if (st.abn & 0xFFu) {                                 // leave the whole tile to the generic kernel
-            if (tid == 0) a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
+            if (tid == 0) {
+                a.defer_list[atomicAdd(a.defer_count, 1u)] = t;
+                // (those a wider halo would have kept: counted apart, the host widens the halos of the following blocks)
+                const uint32_t why = st.abn & 0xFFu;
+                if (why == AB_NO_PREV || why == AB_OPEN_GROUP) atomicAdd(a.defer_count + 1, 1u);
+            }
 #if defined(MKT_STAMPS)
             // diagnostic build: why tiles are deferred -- counts per reason code AB_* (1 .. 12), 16 bits apiece, in stamps[12 .. 14]
             if (tid == 0 && a.stamps) { const uint32_t r = (st.abn & 0xFFu) - 1u; if (r < 12u) atomicAdd(&a.stamps[12 + r / 4u], 1ull << (16u * (r & 3u))); }
@@ -947,6 +952,7 @@ __global__ __launch_bounds__(NTF) void k_finish(KArgs a) {
         if (blockIdx.x == 0) {
             r->pair_bytes = pb; r->emitted = em; r->sam_bytes = sb; r->sc = sc; r->nregions = (uint32_t)a.nregions;
             r->pad = a.defer_count ? *a.defer_count : 0u;         // tiles the lean kernel deferred
+            r->pad2 = a.defer_count ? a.defer_count[1] : 0u;      // ... those of them for a halo that was too narrow
             r->tiles = a.ntiles;
             const int last = *a.last_tile - 1;
             if (last >= 0) r->last = a.tile_last[last];

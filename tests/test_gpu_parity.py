@@ -227,6 +227,39 @@ def test_resident_path_replays_a_block_when_the_lines_get_shorter():
     assert util.canon(pairs)[:len(util.canon(pshort))] == util.canon(pshort) or set(pshort.splitlines()) <= set(pairs.splitlines())
 
 
+def test_long_groups_make_the_host_widen_the_halos():
+    """Read names with nine alignment lines each among ordinary pairs: a group that starts in the last lines of a tile does not end
+    inside the default forward halo (7 lines), the tile goes to the generic kernel (counted apart: BlockResult::pad2), and the host
+    widens the halos of the following blocks (mkt_capi.cpp: adapt_geometry / widen_halos).  The geometry changes in mid-stream: the
+    outputs must equal the oracle's all the same, and over the whole input fewer tiles are deferred than the first block alone defers."""
+    _need_gpu()
+    import random
+    rnd = random.Random(99)
+    seq, qual = "A" * 150, "F" * 150
+    rows = []
+    for g in range(330000):
+        n = 9 if rnd.random() < 0.3 else 2
+        for k in range(n):
+            flag = 65 if k % 2 == 0 else 129
+            rows.append(f"A00123:45:HXXXXXXXX:1:{1101 + g % 50}:{g}:{1000 + g % 977}\t{flag}\tchr{1 + g % 22}\t{100000 + 37 * g + 400 * k}\t60\t150M\t=\t{100000 + 37 * g}\t0\t{seq}\t{qual}\tNM:i:0\n")
+    host = "".join(rows).encode()
+    assert len(host) > 3 * (64 << 20)
+    po, so, lo, ost = util.oracle_run(host, "unc", 4, 0.5, 10, False)
+
+    def run(text):
+        with m.Context("unc", 0.5, 10, False, 4, device=0, block_bytes=64 << 20) as c:
+            p, s, st, log = c.run_bytes(text, chunk=16 << 20)
+            tm = c.timing()
+        return p, log, tm.tiles, tm.deferred_tiles
+
+    p, log, tiles, deferred = run(host)
+    assert log == lo and len(p) == len(po) and _line_multiset_checksum(p) == _line_multiset_checksum(po)
+    first = host[:host.rfind(b"\n", 0, 60 << 20) + 1]            # (about the first block)
+    _p1, _l1, tiles1, deferred1 = run(first)
+    assert deferred1 * 500 > tiles1, (tiles1, deferred1)          # the default halos are too narrow for this input ...
+    assert deferred * tiles1 < 0.7 * deferred1 * tiles, (tiles, deferred, tiles1, deferred1)      # ... and what follows the first block does better
+
+
 def test_two_contexts_as_two_shards():
     """The sharded bookkeeping (group offsets, Q1 on the last shard only) with real kernels: 2 contexts on one GPU."""
     _need_gpu()
