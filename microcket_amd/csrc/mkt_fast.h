@@ -40,11 +40,11 @@ constexpr int kLeanLinesTarget = 126;      // lines per window the host aims at:
 // the kernel's capacities.  Halos are sized by what a deferred tile costs: a pass of the generic kernel takes 0.1 - 0.2 ms for a
 // handful of tiles, a tenth of a block's time.  Measured on the bench data: back 5 / forward 7.5 lines: one tile in 21 000
 // deferred (two per 2 GB block); 7.5 / 7.5: one in 170 000 (all "group open at the end of the window").
-// halos in lines: the previous surviving line is almost always one of the six lines in front of the tile, a group that starts in the
-// tile almost always ends within seven lines behind it (one tile in ~10^5 of the bench's data is left to the generic kernel for its
-// halo; 7.5 / 8.75 lines: none, 4 / 5 lines: one in 10^3 -- profiles/r03_raw/halo_sweep.txt).  An input whose groups are longer makes
-// the host widen them (mkt_capi.cpp: adapt_geometry)
-constexpr double kLeanHaloBackLines = 6.0, kLeanHaloFwdLines = 7.0;
+// halos in lines.  Narrower halos mean more own lines per window and fewer tiles (6 / 7 lines: k_fast -3.4 %), but a tile whose halo is
+// too narrow goes to the generic kernel, which takes ~150 us for it while the GPU waits: at 6 / 7 lines one tile in 10^5 of the bench's
+// data (0.75 per 45 000-tile block) made the whole step 4 % SLOWER; at 7.5 / 8.75 none of 6.5 M is deferred (profiles/r03_raw/
+// halo_sweep.txt, r03_kernel_variants.txt).  An input whose groups are longer makes the host widen them (mkt_capi.cpp: adapt_geometry)
+constexpr double kLeanHaloBackLines = 7.5, kLeanHaloFwdLines = 8.75;
 MKT_HD TileDims lean_dims(double avg) {
     if (avg < 48.0) avg = 48.0;
     if (avg > 4096.0) avg = 4096.0;

@@ -229,7 +229,7 @@ def test_resident_path_replays_a_block_when_the_lines_get_shorter():
 
 def test_long_groups_make_the_host_widen_the_halos():
     """Read names with nine alignment lines each among ordinary pairs: a group that starts in the last lines of a tile does not end
-    inside the default forward halo (7 lines), the tile goes to the generic kernel (counted apart: BlockResult::pad2), and the host
+    inside the default forward halo (8.75 lines), the tile goes to the generic kernel (counted apart: BlockResult::pad2), and the host
     widens the halos of the following blocks (mkt_capi.cpp: adapt_geometry / widen_halos).  The geometry changes in mid-stream: the
     outputs must equal the oracle's all the same, and over the whole input fewer tiles are deferred than the first block alone defers."""
     _need_gpu()

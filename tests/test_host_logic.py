@@ -160,7 +160,7 @@ def test_chromosome_name_order_short_and_long_names():
 def test_tile_geometry_follows_the_line_length():
     """mkt_fast.h: lean_dims -- the window holds about 126 lines whatever the line length (the lane-per-line phases run two full waves),
     every part is a multiple of 16 bytes inside the kernel's capacities, the window a multiple of 1 KiB where the caps leave room (the
-    scan's full-window path), halos of 6 / 7 lines; monotone in the line length."""
+    scan's full-window path), halos of 7.5 / 8.75 lines; monotone in the line length."""
     import ctypes as C
     util.ensure_built()
     lib = C.CDLL(util.EMUL_SO)
@@ -176,7 +176,7 @@ def test_tile_geometry_follows_the_line_length():
         prev = w
         if tile < mt and hb < mb and hf < mf and tile > 2048 and hb > 256 and hf > 512:      # nothing capped: ~126 lines, 1 KiB granularity
             assert w % 1024 == 0 and abs(w - 126 * avg) <= 512 + 48, (avg, w, w / avg)      # (nearest KiB)
-            assert abs(hb - 6 * avg) <= 16 and abs(hf - 7 * avg) <= 16, (avg, hb, hf)
+            assert abs(hb - 7.5 * avg) <= 16 and abs(hf - 8.75 * avg) <= 16, (avg, hb, hf)
     o = (C.c_uint32 * 6)()
     lib.emul_lean_dims(409.0, o)                                         # SURVEY's 150 bp bwa line
     assert 40000 <= o[0] <= 49152
