@@ -448,7 +448,7 @@ static int enqueue_block(mkt_ctx* c, const uint8_t* d_text, size_t n, int cfg, c
         HIPCHK(c, hipEventRecord(e1, c->stream));
         KArgs b = a;
         b.use_list = 1; b.ticket = ticket2;
-        HIPCHK(c, launch_tiles(b, cfg, ntiles < 256u ? (int)ntiles : 256, c->stream));
+        HIPCHK(c, launch_tiles(b, cfg, ntiles < 96u ? (int)ntiles : 96, c->stream));
     } else {
         HIPCHK(c, launch_tiles(a, cfg, grid, c->stream));
         HIPCHK(c, hipEventRecord(e1, c->stream));
