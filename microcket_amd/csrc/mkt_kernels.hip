@@ -261,13 +261,25 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
         const TextView tv = tile_view(st, a.text, n, G);
 
         // ---- stage window in LDS, build the newline / whitespace bitmaps ------------------------
-        for (uint32_t v = tid; v < (uint32_t)NM16; v += NT) {
+        // (all loads of a lane first: one memory round trip for the window instead of one per iteration)
+        constexpr int SPT = (NM16 + NT - 1) / NT;
+        uint4 xs[SPT];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t v = (uint32_t)tid + (uint32_t)q * NT;
+            const uint32_t go = G.w0 + (v << 4);
+            xs[q] = *reinterpret_cast<const uint4*>(a.text + ((v < nvec && go + 16u <= n) ? go : 0u));      // (no conditional load: vector 0 again, unused)
+        }
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t v = (uint32_t)tid + (uint32_t)q * NT;
+            if (v >= (uint32_t)NM16) continue;
             uint32_t mnl = 0, mws = 0;
             if (v < nvec) {
                 const uint32_t go = G.w0 + (v << 4);
                 uint4 x;
                 if (go + 16u <= n) {
-                    x = *reinterpret_cast<const uint4*>(a.text + go);
+                    x = xs[q];
                 } else {
                     uint32_t w[4] = {0, 0, 0, 0};
                     for (uint32_t b = 0; go + b < n; ++b) w[b >> 2] |= (uint32_t)a.text[go + b] << ((b & 3u) * 8u);
@@ -403,10 +415,11 @@ __global__ __launch_bounds__(NT) void k_tiles(KArgs a) {
             ph_account(st, tv, P, s_out, t, i);
             ph_last(st, &a.tile_last[t], i);
         }
-        {   // .pairs bytes: one lane per output byte, coalesced stores
+        {   // .pairs bytes: one lane per reported pair writes its line (a lane per output BYTE, with a search for the pair and a walk
+            // over its fields behind every byte, was 40 % of a tile's time here)
             const uint32_t total = st.sums.pair_bytes;
             const uint64_t go = st.base.pair_bytes;
-            if (go + total <= s_out.pairs_cap) { for (uint32_t k = tid; k < total; k += NT) s_out.pairs[go + k] = tile_pair_byte(st, tv, k); }
+            if (go + total <= s_out.pairs_cap) { for (uint32_t e = tid; e < st.sums.emitted; e += NT) tile_emit_line(st, tv, e, s_out.pairs + go); }
             else if (tid == 0 && total) lds_or(&st.err, E_PAIRS_CAP);
         }
         if (P.write_sam) {   // contiguous groups: straight byte-range copies

@@ -566,6 +566,22 @@ template <class Cfg> MKT_HD uint8_t tile_pair_byte(const TileState<Cfg>& st, con
     return pair_line_byte(tv, st.off[i] + st.qn_off[i], st.qn_len[i], v, k - g.x_pair[i]);
 }
 
+// the whole .pairs line of the e-th reported pair of the tile, by ONE lane (the same bytes as tile_pair_byte, without a search and a
+// field walk per byte: the lanes of a workgroup write the tile's lines side by side)
+template <class Cfg> MKT_HD void tile_emit_line(const TileState<Cfg>& st, const TextView& tv, uint32_t e, uint8_t* tile_out) {
+    const auto& g = st.u.g;
+    const uint32_t i = g.em_idx[e];
+    const uint32_t info = g.g_info[i];
+    Verdict v;
+    v.counter = info & GI_COUNTER; v.emit = true;
+    v.chrA_off = g.g_chrA[i]; v.chrA_len = g.g_chrA_len[i]; v.chrB_off = g.g_chrB[i]; v.chrB_len = g.g_chrB_len[i];
+    v.posA = g.g_posA[i]; v.posB = g.g_posB[i];
+    v.sA = (info & GI_SA_MINUS) ? '-' : '+'; v.sB = (info & GI_SB_MINUS) ? '-' : '+';
+    const uint32_t qn = st.off[i] + st.qn_off[i], ql = st.qn_len[i], plen = g.g_plen[i];
+    uint8_t* d = tile_out + g.x_pair[i];
+    for (uint32_t k = 0; k < plen; ++k) *MKT_GLOBAL(uint8_t, d + k) = pair_line_byte(tv, qn, ql, v, k);
+}
+
 // the tile's last group, for the host's Q1 bookkeeping
 template <class Cfg> MKT_HD void ph_last(const TileState<Cfg>& st, TileLast* tl, uint32_t i) {
     const auto& g = st.u.g;
